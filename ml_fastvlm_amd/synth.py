@@ -1,0 +1,118 @@
+"""Seeded, non-degenerate synthetic weights and inputs for FastViTHD + projector.
+
+There is no network in the build/bench environment, so no FastVLM checkpoint can
+be fetched; parity and throughput are therefore established on synthetic
+weights.  The reference's default init is a useless oracle:
+`layer_scale = 1e-5` (`mci.py:1058,1132`) turns every block into an identity and
+hides ConvFFN / attention bugs.  The values drawn here keep activations O(1)
+through all 11 network entries while exercising every term:
+
+* conv / linear weights and biases: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (the
+  PyTorch default bound), RepMixer / RepCPE kernels get +1 on the centre tap
+  (they are "identity + branch" after re-parameterisation, `mci.py:819-859`,
+  `:1000-1039`; the branch part is scaled by 0.3 so 24 stacked mixers do not blow up);
+* gains on the non-residual convs (stem x3, PatchEmbed x2.5, conv_exp x3) and on qkv (x3,
+  so attention logits have std ~3 and softmax is far from uniform), tuned so that every
+  network entry's output has rms 0.4-1.0 and every stage changes its input by 20-100 %
+  (measured with the reference, see `oracle/make_golden.py` output);
+* layer scales U[0.1, 0.6]; BatchNorm running_var U[0.5, 1.5], running_mean
+  N(0, 0.1^2), gamma U[0.8, 1.2], beta N(0, 0.1^2); LayerNorm likewise.
+
+Each tensor has its own CPU generator seeded from (seed, crc32(key)), so the
+values do not depend on generation order and are identical on every machine
+with the same torch build (the GPU box runs this same image).
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from collections import OrderedDict
+from typing import Dict
+
+import torch
+
+from . import fastvithd_spec as spec
+
+
+def _gen(seed: int, key: str) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed * 1000003 + zlib.crc32(key.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def _uniform(shape, lo, hi, g):
+    return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+
+def _normal(shape, std, g):
+    return torch.randn(shape, generator=g, dtype=torch.float32) * std
+
+
+def synthetic_tensor(key: str, shape, kind: str, seed: int) -> torch.Tensor:
+    g = _gen(seed, key)
+    leaf = key.rsplit(".", 1)[-1]
+    if kind == "buffer_i64":
+        return torch.zeros(shape, dtype=torch.int64)
+    if "layer_scale" in leaf:
+        return _uniform(shape, 0.1, 0.6, g)
+    if ".bn." in key or ".norm." in key:
+        if leaf == "weight":
+            return _uniform(shape, 0.8, 1.2, g)
+        if leaf == "running_var":
+            return _uniform(shape, 0.5, 1.5, g)
+        return _normal(shape, 0.1, g)          # bias / running_mean
+    if key == "head.proj":
+        return _normal(shape, shape[0] ** -0.5, g)
+    if leaf == "weight":
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        b = 1.0 / math.sqrt(fan_in)
+        w = _uniform(shape, -b, b, g)
+        # re-parameterised "identity + branch" depthwise kernels (RepMixer, RepCPE)
+        if key.endswith("token_mixer.reparam_conv.weight") or (
+            key.startswith("network.") and key.count(".") == 3 and key.endswith(".reparam_conv.weight")
+        ):
+            k = shape[-1]
+            w *= 0.3
+            w[:, 0, k // 2, k // 2] += 1.0
+        elif key.startswith("patch_embed."):
+            w *= 3.0            # stem: GELU roughly halves small activations
+        elif ".proj.0." in key or ".proj.1." in key:
+            w *= 2.5            # PatchEmbed convs (non-residual)
+        elif key == "conv_exp.reparam_conv.weight":
+            w *= 3.0
+        elif key.endswith("token_mixer.qkv.weight"):
+            w *= 3.0            # logit std ~3: a peaky softmax that exercises the online rescale
+        return w
+    if leaf == "bias":
+        # bound from the sibling weight's fan_in is not known here; 0.05 keeps things O(1)
+        return _uniform(shape, -0.05, 0.05, g)
+    raise KeyError(f"no synthetic rule for {key}")
+
+
+def synthetic_state_dict(seed: int = 1234) -> "OrderedDict[str, torch.Tensor]":
+    """FastViT-relative keys (`patch_embed.0.reparam_conv.weight`, ...)."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for key, (shape, kind) in spec.param_spec().items():
+        sd[key] = synthetic_tensor(key, shape, kind, seed)
+    return sd
+
+
+def synthetic_projector_state_dict(hidden: int, seed: int = 1234, mm_hidden: int = spec.OUT_DIM) -> Dict[str, torch.Tensor]:
+    """`mlp2x_gelu` projector (`multimodal_projector/builder.py:23-30`): keys 0.*, 2.*"""
+    shapes = {
+        "0.weight": (hidden, mm_hidden),
+        "0.bias": (hidden,),
+        "2.weight": (hidden, hidden),
+        "2.bias": (hidden,),
+    }
+    return {k: synthetic_tensor("mm_projector." + k, s, "param", seed) for k, s in shapes.items()}
+
+
+def synthetic_images(batch: int, res: int, seed: int = 0, dtype=torch.float32) -> torch.Tensor:
+    """Values in [0,1): the tower's processor rescales by 1/255 with mean 0 / std 1
+    (`mobileclip_encoder.py:45-49`)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.rand((batch, 3, res, res), generator=g, dtype=torch.float32).to(dtype)

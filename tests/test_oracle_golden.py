@@ -1,0 +1,86 @@
+"""Pins `oracle/fastvithd_oracle.py` (the CPU restatement) against fixtures produced by the
+reference itself (`oracle/make_golden.py`), and against the live reference when it is mounted."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ml_fastvlm_amd import fastvithd_spec as spec
+from ml_fastvlm_amd import synth
+from oracle import fastvithd_oracle as O
+from oracle import ref_import
+
+
+def _rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def test_param_spec_matches_reference_keys(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "keys.json")))
+    mine = spec.param_spec()
+    assert ref["n_tensors"] == 629 == len(mine)
+    assert list(mine.keys()) == list(ref["keys"].keys()), "key set / registration order differs"
+    for k, (shape, kind) in mine.items():
+        assert list(shape) == ref["keys"][k]["shape"], k
+        assert (kind == "buffer_i64") == (ref["keys"][k]["dtype"] == "int64"), k
+    n_params = sum(int(np.prod(s)) for s, kind in mine.values() if kind == "param")
+    assert n_params == ref["n_params"]
+
+
+def test_oracle_matches_reference_r256(golden_dir, synth_sd):
+    g = np.load(os.path.join(golden_dir, "tower_r256_b2.npz"))
+    assert int(g["weight_seed"]) == 1234
+    x = synth.synthetic_images(2, 256, seed=int(g["image_seed"]))
+    taps = []
+    out = O.tower_forward(x, synth_sd, taps=taps)
+    assert out.shape == (2, 16, 3072)
+    assert _rel_l2(out, torch.from_numpy(g["out"])) < 2e-6
+    stride = int(g["tap_stride"])
+    assert len(taps) == 13
+    for i, t in enumerate(taps):
+        assert list(t.shape) == list(g[f"tap{i:02d}_shape"]), i
+        assert _rel_l2(t.flatten()[::stride], torch.from_numpy(g[f"tap{i:02d}"])) < 2e-6, i
+
+
+def test_oracle_matches_reference_r1024(golden_dir, synth_sd):
+    g = np.load(os.path.join(golden_dir, "tower_r1024_b1.npz"))
+    x = synth.synthetic_images(1, 1024, seed=int(g["image_seed"]))
+    out = O.tower_forward(x, synth_sd)
+    assert out.shape == (1, 256, 3072)
+    assert _rel_l2(out[:, ::8], torch.from_numpy(g["out_tok8"])) < 2e-6
+    assert abs(out.double().pow(2).sum().sqrt().item() - float(g["l2"])) / float(g["l2"]) < 1e-6
+    tl2 = out.double().pow(2).sum(-1).sqrt()[0]
+    assert torch.allclose(tl2, torch.from_numpy(g["token_l2"]), rtol=1e-5)
+
+
+def test_oracle_projector(golden_dir):
+    g = np.load(os.path.join(golden_dir, "projector_h896.npz"))
+    pj = synth.synthetic_projector_state_dict(896, int(g["weight_seed"]))
+    y = O.projector(torch.from_numpy(g["tokens"]), pj)
+    assert _rel_l2(y, torch.from_numpy(g["out"])) < 2e-6
+
+
+def test_oracle_list_input_equals_batch(synth_sd):
+    # mobileclip_encoder.py:78-83: a list is a loop of B=1 calls; images are independent.
+    x = synth.synthetic_images(2, 128, seed=3)
+    a = O.tower_forward(x, synth_sd)
+    b = torch.cat([O.tower_forward(x[i:i + 1], synth_sd) for i in range(2)], 0)
+    assert _rel_l2(a, b) < 1e-5
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="reference tree not mounted")
+def test_oracle_matches_live_reference_odd_shapes(synth_sd):
+    """Live check at a non-square-count resolution (192 -> 3x3 tokens) and fp64."""
+    tower = ref_import.build_reference_tower(192)
+    tower.vision_tower.model.load_state_dict(synth_sd, strict=True)
+    x = synth.synthetic_images(1, 192, seed=5)
+    ref = tower(x)
+    assert ref.shape == (1, 9, 3072)
+    assert _rel_l2(O.tower_forward(x, synth_sd), ref) < 2e-6
+    tower.double()
+    ref64 = tower(x.double())
+    got64 = O.tower_forward(x.double(), synth_sd, dtype=torch.float64)
+    assert _rel_l2(got64, ref64) < 1e-12
