@@ -1,0 +1,119 @@
+/* fvhd.h - C ABI of libfvhd.so: the MI355X (gfx950) FastViTHD encode_images() path.
+ *
+ * The reference (apple/ml-fastvlm) is pure Python and has no FFI for this path; the boundary it
+ * exposes is the duck-typed nn.Module `MobileCLIPVisionTower`
+ * (llava/model/multimodal_encoder/mobileclip_encoder.py:13-116) created by `build_vision_tower`
+ * (llava/model/multimodal_encoder/builder.py:6-19) and called from `encode_images`
+ * (llava/model/llava_arch.py:141-144).  This header is what a binding for that boundary binds to;
+ * `ml_fastvlm_amd/_lib.py` is the ctypes stub, `INTEGRATION.md` shows the reference-side patch.
+ *
+ * Conventions: every function returns 0 on success and a non-zero code on failure
+ * (`fvhd_last_error()` gives a thread-local message); no C++ exception crosses the boundary; all
+ * `void*` data arguments are DEVICE pointers unless the name says `host_`; work is enqueued on the
+ * caller's HIP stream and never synchronises the device; the caller owns input/output buffers, the
+ * context owns packed weights and workspace.  A context is bound to one device and is not
+ * thread-safe (one context per stream/thread; the reference's callers enter `forward` one at a
+ * time, llava/serve/model_worker.py:168-187).
+ */
+#ifndef FVHD_H
+#define FVHD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fvhd_ctx fvhd_ctx;
+typedef void* fvhd_stream_t; /* hipStream_t */
+
+/* element types of caller-visible tensors */
+#define FVHD_F32 0
+#define FVHD_F16 1
+#define FVHD_BF16 2
+
+/* GEMM epilogues (fvhd_op_gemm) */
+#define FVHD_EPI_NONE 0          /* out = A.W^T                                   (MHSA.qkv, mci.py:668) */
+#define FVHD_EPI_BIAS 1          /* out = A.W^T + b                               (projector Linear #2)   */
+#define FVHD_EPI_BIAS_GELU 2     /* out = gelu(A.W^T + b)                         (fc1, 1x1 convs, projector Linear #1) */
+#define FVHD_EPI_BIAS_LS_RESID 3 /* out = resid + ls * (A.W^T + b)                (fc2 / proj + layer scale + skip) */
+
+int fvhd_version(void);
+const char* fvhd_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------------
+ * Replaces MobileCLIPVisionTower.__init__/load_model (mobileclip_encoder.py:14-58): one context per
+ * (device, input resolution).  `image_size` is the R of the tower name `mobileclip_l_<R>`
+ * (mobileclip_encoder.py:20), a multiple of 64.  Workspace is sized for `max_batch` images and
+ * grows on demand. */
+int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch);
+void fvhd_destroy(fvhd_ctx* ctx);
+
+/* Hand one tensor of the reference's inference-mode state dict to the library
+ * (key relative to the FastViT module, e.g. "network.7.0.token_mixer.qkv.weight"; the 629 keys of
+ * tests/golden/keys.json).  `host_data` is contiguous fp32 HOST memory in the reference's own
+ * layout ([out,in,kh,kw] for convs, [out,in] for linears); it is copied before the call returns.
+ * Replaces nn.Module.load_state_dict for the tower (model/builder.py:131). */
+int fvhd_set_tensor(fvhd_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+
+/* Fold eval-mode BatchNorm into the dw7x7 taps (mci.py:901-907), transpose depthwise taps to
+ * [kh*kw][C], round GEMM weights to bf16, upload.  Fails if any required tensor is missing. */
+int fvhd_finalize_weights(fvhd_ctx* ctx);
+
+/* mlp2x_gelu projector weights (multimodal_projector/builder.py:23-30): host fp32,
+ * w0 [hidden, mm_hidden], b0 [hidden], w2 [hidden, hidden], b2 [hidden]. */
+int fvhd_set_projector(fvhd_ctx* ctx, const float* host_w0, const float* host_b0, const float* host_w2,
+                       const float* host_b2, int mm_hidden, int hidden);
+
+/* ---- hot path -----------------------------------------------------------------------------------
+ * MobileCLIPVisionTower.forward_images + feature_select (mobileclip_encoder.py:60-88):
+ * images [B,3,R,R] NCHW contiguous of `img_dtype` -> tokens_out [B,(R/64)^2,3072] of `out_dtype`. */
+int fvhd_encode(fvhd_ctx* ctx, const void* images, int img_dtype, int batch, void* tokens_out, int out_dtype,
+                fvhd_stream_t stream);
+
+/* mm_projector forward (llava_arch.py:143): tokens [rows, mm_hidden] -> out [rows, hidden]. */
+int fvhd_project(fvhd_ctx* ctx, const void* tokens, int in_dtype, int rows, void* out, int out_dtype,
+                 fvhd_stream_t stream);
+
+/* encode_images (llava_arch.py:141-144) = tower then projector, tokens kept in bf16 in workspace. */
+int fvhd_encode_images(fvhd_ctx* ctx, const void* images, int img_dtype, int batch, void* out, int out_dtype,
+                       fvhd_stream_t stream);
+
+/* geometry helpers (mobileclip_encoder.py:106-116) */
+int fvhd_num_tokens(const fvhd_ctx* ctx);   /* (R/64)^2 */
+int fvhd_hidden_size(const fvhd_ctx* ctx);  /* 3072     */
+
+/* ---- measurement --------------------------------------------------------------------------------
+ * With profiling on, every kernel launch inside fvhd_encode/fvhd_project is bracketed by HIP events
+ * on the caller's stream.  fvhd_profile_read synchronises those events and returns, per kernel
+ * class, the accumulated milliseconds and launch count since the last reset.  Class names:
+ * "stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv", "gemm_proj",
+ * "layernorm", "attention", "head", "projector". */
+int fvhd_profile_enable(fvhd_ctx* ctx, int on);
+int fvhd_profile_reset(fvhd_ctx* ctx);
+int fvhd_profile_read(fvhd_ctx* ctx, int max_classes, const char** names, double* ms, int64_t* launches,
+                      int* n_classes);
+
+/* ---- single ops (unit-test entry points; device pointers, packed layouts as documented) ---------- */
+/* depthwise conv, NHWC bf16: x [B,H,W,Cin] -> y [B,OH,OW,Cin*mult]; w fp32 [K*K][Cout]; bias fp32 [Cout] or NULL.
+ * (K,stride,mult,gelu) in {(3,1,1,0),(3,2,1,1),(7,1,1,0),(7,2,2,1),(3,1,2,0)}  - mci.py:808-811, 575-586, 921, 992-995, 442-451, 1401-1411 */
+int fvhd_op_dwconv(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias,
+                   int B, int H, int W, int Cin, int K, int stride, int mult, int gelu);
+/* out[M,N] = epi(A[M,K] . Wt[N,K]^T): A, Wt, resid bf16; bias, ls fp32 [N]; K % 32 == 0, N % 16 == 0. */
+int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, const float* ls,
+                 const void* resid, void* out, int M, int N, int K, int epilogue, int out_dtype);
+/* LayerNormChannel (mci.py:617-623) on NHWC rows: x,y [M,C] bf16; w,b fp32 [C]. */
+int fvhd_op_layernorm(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* b, int M, int C, float eps);
+/* MHSA core (mci.py:670-679): qkv [B*N,3C] bf16 -> out [B*N,C] bf16, head_dim 32. */
+int fvhd_op_attention(fvhd_stream_t stream, const void* qkv, void* out, int B, int N, int C);
+/* stem[0] (mci.py:563-574): img [B,3,R,R] of dtype -> out [B,R/2,R/2,96] bf16; w fp32 [27][96] (k = ci*9+ky*3+kx). */
+int fvhd_op_stem_conv(fvhd_stream_t stream, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R);
+/* SEBlock + GELU of conv_exp (mci.py:72-81,198): y [B,T,C] bf16 -> out [B,T,C] of out_dtype;
+ * pooled, scale: fp32 scratch [B,C]; wr fp32 [RD][C]; we fp32 [C][RD]. */
+int fvhd_op_se_head(fvhd_stream_t stream, const void* y, float* pooled, float* scale, const float* wr, const float* br,
+                    const float* we, const float* be, void* out, int out_dtype, int B, int T, int C, int RD);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVHD_H */

@@ -1,0 +1,72 @@
+"""Builds `ml_fastvlm_amd/libfvhd.so` (the C-ABI library of include/fvhd.h) with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting
+`.so` is git-ignored but travels with the tree to the GPU box.  Objects are rebuilt only when a
+source (or a header) is newer.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+BUILD = os.path.join(CSRC, "build")
+LIB = os.path.join(PKG, "libfvhd.so")
+SOURCES = ["dwconv.hip", "gemm.hip", "attention.hip", "stem_head.hip", "fvhd_api.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=fast", "-fno-gpu-rdc"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain is required to build libfvhd.so)")
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(PKG), "include", "fvhd.h"))
+    headers.append(os.path.abspath(__file__))
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn:
+                print(warn, file=sys.stderr)
+    if force or jobs or _newer(LIB, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,210 @@
+// LayerNormChannel and multi-head self-attention of the FastViTHD AttentionBlocks (stages 3, 4).
+//
+//   LayerNormChannel.forward   mci.py:617-623   per-pixel LN over C, biased variance, eps 1e-5
+//   MHSA.forward               mci.py:661-685   softmax((q * 32^-0.5) k^T) v, head_dim 32, no qkv bias
+//
+// NHWC makes the channel axis contiguous, so LN is one wave per token row (two-pass in registers,
+// wave64 butterfly reductions) and the qkv GEMM output [B*N, 3C] already has q/k/v of head h at
+// column offsets h*32, C + h*32, 2C + h*32 - attention reads it in place with a row stride of 3C.
+//
+// Attention kernel (flash-style, one (image, head, 64-query block) per 256-thread workgroup):
+//   * each wave owns 16 queries; Q fragment lives in registers (one 16-B load per lane).
+//   * K/V stream through LDS in 64-key tiles, double buffered; K tile row-major [64][32] with the
+//     same XOR slot swizzle as the GEMM (conflict-free ds_read_b128 fragment reads); V is stored
+//     TRANSPOSED in LDS ([32 d][64 keys], 136-B row stride -> conflict-free ds_read_b64) because the
+//     PV contraction runs over keys and an MFMA operand needs the contraction index contiguous
+//     inside a lane.
+//   * scores are computed transposed, S^T = K . Q^T (mfma(Kfrag, Qfrag)): the C/D layout then gives
+//     every lane 4 consecutive keys of ONE query (q = lane & 15), so the softmax row statistics are
+//     lane-local plus two xor-shuffles (lanes q, q+16, q+32, q+48), and two S^T fragments are
+//     already a valid B operand of O^T = V^T . P^T for a permuted key order - the same permutation
+//     the V^T fragment is read with - so P never leaves registers.
+//   * online softmax in fp32 with exp2 (scale * log2 e folded), P rounded to bf16 for the MFMA,
+//     row sums accumulated from the fp32 values, O^T accumulators fp32; out-of-range keys are
+//     masked to -1e30, out-of-range queries are not stored (any N works, e.g. 16 or 576).
+#include "fvhd_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm over the channel axis: x [M, C] bf16 -> y [M, C] bf16.  One wave per row, C % 4 == 0.
+template <int VPL>   // 8-byte vectors per lane (C = 256 * VPL when exact)
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        int M, int C, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16* xr = x + (size_t)row * C;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+            v[i] = bf4_to_f32(*(const bf16x4*)(xr + c));
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    bf16* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+            const f32x4 wv = *(const f32x4*)(w + c), bv = *(const f32x4*)(b + c);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * wv[k] + bv[k];
+            *(bf16x4*)(yr + c) = f32_to_bf4(o);
+        }
+    }
+}
+
+extern "C" int fvhd_launch_layernorm(hipStream_t st, const void* x, void* y, const float* w, const float* b,
+                                     int M, int C, float eps)
+{
+    if (C % 4 || C > 256 * 8) return (int)hipErrorInvalidValue;
+    const int vpl = (C + 255) / 256;
+    dim3 grid((M + 3) / 4), block(256);
+    const bf16* xi = (const bf16*)x;
+    bf16* yo = (bf16*)y;
+#define LN_CASE(V) case V: hipLaunchKernelGGL((layernorm_kernel<V>), grid, block, 0, st, xi, yo, w, b, M, C, eps); break;
+    switch (vpl) { LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8) }
+#undef LN_CASE
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define ATT_D 32
+#define ATT_KT 64          // keys per tile
+#define ATT_QB 64          // queries per workgroup (16 per wave)
+#define ATT_VT_STRIDE 136  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                        int N, int C, float scale_log2e)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * (ATT_KT * 64 + ATT_D * ATT_VT_STRIDE)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const size_t row_stride = (size_t)3 * C;
+    const bf16* base = qkv + (size_t)b * N * row_stride + h * ATT_D;
+
+    // Q fragment (B operand: n = query = lr, k = d = 8g..8g+7)
+    const int q_idx = qb * ATT_QB + wave * 16 + lr;
+    const bf16x8 qf = *(const bf16x8*)(base + (size_t)min(q_idx, N - 1) * row_stride + g * 8);
+
+    // staging assignment: thread -> (key = tid>>2, 16-B chunk = tid&3) of the K and V tiles
+    const int skey = tid >> 2, sch = tid & 3;
+    const bf16* kptr = base + C + sch * 8;
+    const bf16* vptr = base + 2 * C + sch * 8;
+    const int k_dst = skey * 64 + ((sch ^ ((0 - (skey >> 2)) & 3)) << 4);
+
+    f32x4 o_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // O^T[d = df*16 + 4g + r][q = lr]
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (N + ATT_KT - 1) / ATT_KT;
+    u32x4 rk, rv;
+    {
+        const int key = min(skey, N - 1);
+        rk = *(const u32x4*)(kptr + (size_t)key * row_stride);
+        rv = *(const u32x4*)(vptr + (size_t)key * row_stride);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        char* kbuf = lds + (t & 1) * (ATT_KT * 64 + ATT_D * ATT_VT_STRIDE);
+        char* vbuf = kbuf + ATT_KT * 64;
+        *(u32x4*)(kbuf + k_dst) = rk;
+        {
+            const bf16x8 vv = __builtin_bit_cast(bf16x8, rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(bf16*)(vbuf + (sch * 8 + i) * ATT_VT_STRIDE + skey * 2) = vv[i];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            const int key = min((t + 1) * ATT_KT + skey, N - 1);
+            rk = *(const u32x4*)(kptr + (size_t)key * row_stride);
+            rv = *(const u32x4*)(vptr + (size_t)key * row_stride);
+        }
+
+        // S^T[key][q] for 4 key fragments of 16
+        f32x4 s[4];
+        float mx = -1e30f;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            const int krow = kf * 16 + lr;
+            const bf16x8 kfr = *(const bf16x8*)(kbuf + krow * 64 + ((g ^ ((0 - (krow >> 2)) & 3)) << 4));
+            s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * ATT_KT + kf * 16 + g * 4 + r;
+                if (key >= N) s[kf][r] = -1e30f;
+                mx = fmaxf(mx, s[kf][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[2];     // B operand of O^T = V^T . P^T: n = q = lr, k-slot j <-> key (j<4 ? 4g+j : 16+4g+j-4) of chunk c
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x8 p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __builtin_amdgcn_exp2f((s[2 * c][r] - m_new) * scale_log2e);
+                p[4 + r] = __builtin_amdgcn_exp2f((s[2 * c + 1][r] - m_new) * scale_log2e);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) psum += p[r];
+            pf[c] = f32_to_bf8(p);
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int df = 0; df < 2; ++df) {
+            o_acc[df] *= alpha;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // A operand: row = d = df*16 + lr, k-slot j <-> same key permutation as pf
+                const char* vr = vbuf + (df * 16 + lr) * ATT_VT_STRIDE + (c * 32 + g * 4) * 2;
+                const bf16x4 lo = *(const bf16x4*)(vr);
+                const bf16x4 hi = *(const bf16x4*)(vr + 32);
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], o_acc[df], 0, 0, 0);
+            }
+        }
+        // no second barrier: the next iteration writes the OTHER buffer, and the buffer written two
+        // iterations from now is only touched after every wave has passed the next __syncthreads().
+    }
+
+    if (q_idx < N) {
+        const float inv = 1.0f / l_run;
+        bf16* orow = out + ((size_t)b * N + q_idx) * C + h * ATT_D;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+            *(bf16x4*)(orow + df * 16 + g * 4) = f32_to_bf4(o_acc[df] * inv);
+    }
+}
+
+// qkv [B*N, 3C] bf16 (q | k | v, head h at columns h*32) -> out [B*N, C] bf16.  C % 32 == 0.
+extern "C" int fvhd_launch_attention(hipStream_t st, const void* qkv, void* out, int B, int N, int C)
+{
+    if (C % ATT_D || B <= 0 || N <= 0) return (int)hipErrorInvalidValue;
+    dim3 grid((N + ATT_QB - 1) / ATT_QB, C / ATT_D, B);
+    const float scale_log2e = 0.17677669529663687f * 1.4426950408889634f;   // 32^-0.5 * log2(e)
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, C, scale_log2e);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,677 @@
+// C ABI (include/fvhd.h): context, weight packing, workspace and the launch sequence of the
+// FastViTHD encode_images() path.  The sequence below is the reference's
+// FastViT.forward (mci.py:1427-1451) with every module replaced by its gfx950 kernel; the block
+// structure follows fastvithd() (mci.py:1454-1478).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fvhd.h"
+
+// ---- kernel launchers (dwconv.hip, gemm.hip, attention.hip, stem_head.hip) -------------------------
+extern "C" {
+int fvhd_launch_dwconv(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int, int, int, int);
+int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
+int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
+int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int);
+int fvhd_launch_stem_conv(hipStream_t, const void*, int, void*, const float*, const float*, int, int);
+int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, const float*, const float*, const float*,
+                        void*, int, int, int, int, int);
+int fvhd_launch_cast_to_bf16(hipStream_t, const void*, int, void*, long);
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg, int code = 1)
+{
+    g_err = msg;
+    return code ? code : 1;
+}
+
+int hip_fail(const char* what, hipError_t e)
+{
+    return fail(std::string(what) + ": " + hipGetErrorString(e), (int)e ? (int)e : 1);
+}
+
+// fastvithd() hyper-parameters, mci.py:1455-1460
+constexpr int kStages = 5;
+constexpr int kLayers[kStages] = {2, 12, 24, 4, 2};
+constexpr int kDims[kStages] = {96, 192, 384, 768, 1536};
+constexpr int kOutDim = 3072;   // cls_ratio 2.0 * 1536 (mci.py:1403)
+constexpr int kSeRd = 192;      // 3072 * 0.0625 (mci.py:49)
+constexpr float kBnEps = 1e-5f, kLnEps = 1e-5f;
+
+uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct Packer {          // builds the packed weight image on the host; offsets are 256-B aligned
+    std::vector<char> buf;
+    size_t reserve(size_t bytes)
+    {
+        size_t off = (buf.size() + 255) & ~(size_t)255;
+        buf.resize(off + bytes);
+        return off;
+    }
+    size_t add_f32(const float* p, size_t n)
+    {
+        size_t off = reserve(n * 4);
+        memcpy(buf.data() + off, p, n * 4);
+        return off;
+    }
+    size_t add_bf16(const float* p, size_t n)
+    {
+        size_t off = reserve(n * 2);
+        uint16_t* d = (uint16_t*)(buf.data() + off);
+        for (size_t i = 0; i < n; ++i) d[i] = f32_to_bf16_rne(p[i]);
+        return off;
+    }
+};
+
+struct DwW { size_t w = 0, b = 0; int K = 0; };                    // taps fp32 [K*K][Cout], bias fp32 [Cout]
+struct GemmW { size_t w = 0, b = 0; int N = 0, K = 0; bool has_bias = false; };
+struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; };
+struct RepBlockW { DwW mixer; FfnW ffn; };
+struct AttnBlockW { size_t ln_w = 0, ln_b = 0, ls1 = 0; GemmW qkv, proj; FfnW ffn; };
+struct DownW { DwW dw; GemmW pw; };
+
+struct Model {
+    size_t stem0_w = 0, stem0_b = 0;
+    DwW stem1;
+    GemmW stem2;
+    std::vector<RepBlockW> rep[3];
+    std::vector<AttnBlockW> att[2];
+    DownW down[4];
+    DwW cpe[2];
+    DwW conv_exp;
+    size_t se_wr = 0, se_br = 0, se_we = 0, se_be = 0;
+};
+
+struct ProfRec { int cls; hipEvent_t a, b; };
+
+const char* kClassNames[] = {"stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv",
+                             "gemm_proj", "layernorm", "attention", "head", "projector"};
+enum { C_STEM, C_DW3, C_DW7, C_DWDOWN, C_FC1, C_FC2, C_1X1, C_QKV, C_PROJ, C_LN, C_ATT, C_HEAD, C_PROJECTOR, C_COUNT };
+
+}  // namespace
+
+struct fvhd_ctx {
+    int device = 0, R = 0, max_batch = 0;
+    std::map<std::string, HostTensor> raw;
+    Model m;
+    char* wdev = nullptr;
+    bool finalized = false;
+    // projector
+    char* pdev = nullptr;
+    GemmW p0, p2;
+    int mm_hidden = 0, hidden = 0;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int ws_batch = 0, ws_hidden = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    double acc_ms[C_COUNT] = {0};
+    int64_t acc_n[C_COUNT] = {0};
+
+    template <typename T> const T* wp(size_t off) const { return (const T*)(wdev + off); }
+};
+
+namespace {
+
+const HostTensor* find(const fvhd_ctx* c, const std::string& key, std::initializer_list<int64_t> shape)
+{
+    auto it = c->raw.find(key);
+    if (it == c->raw.end()) { fail("missing tensor: " + key); return nullptr; }
+    size_t i = 0;
+    bool ok = it->second.shape.size() == shape.size();
+    if (ok) for (int64_t s : shape) ok = ok && (it->second.shape[i++] == s);
+    if (!ok) { fail("bad shape for tensor: " + key); return nullptr; }
+    return &it->second;
+}
+
+// depthwise taps [Cout,1,K,K] -> fp32 [K*K][Cout] (optionally scaled per channel), bias [Cout]
+bool pack_dw(fvhd_ctx* c, Packer& pk, const std::string& wkey, const std::string& bkey, int Cout, int K, DwW* out,
+             const std::vector<float>* ch_scale = nullptr, const std::vector<float>* ch_bias = nullptr)
+{
+    const HostTensor* w = find(c, wkey, {Cout, 1, K, K});
+    if (!w) return false;
+    std::vector<float> t((size_t)K * K * Cout), b((size_t)Cout, 0.f);
+    for (int oc = 0; oc < Cout; ++oc) {
+        const float s = ch_scale ? (*ch_scale)[oc] : 1.0f;
+        for (int k = 0; k < K * K; ++k) t[(size_t)k * Cout + oc] = w->data[(size_t)oc * K * K + k] * s;
+    }
+    if (!bkey.empty()) {
+        const HostTensor* bt = find(c, bkey, {Cout});
+        if (!bt) return false;
+        b = bt->data;
+    }
+    if (ch_bias) b = *ch_bias;
+    out->w = pk.add_f32(t.data(), t.size());
+    out->b = pk.add_f32(b.data(), b.size());
+    out->K = K;
+    return true;
+}
+
+bool pack_gemm(fvhd_ctx* c, Packer& pk, const std::string& wkey, const std::string& bkey, int N, int K, bool conv,
+               GemmW* out)
+{
+    const HostTensor* w = conv ? find(c, wkey, {N, K, 1, 1}) : find(c, wkey, {N, K});
+    if (!w) return false;
+    out->w = pk.add_bf16(w->data.data(), (size_t)N * K);
+    out->N = N;
+    out->K = K;
+    out->has_bias = !bkey.empty();
+    if (out->has_bias) {
+        const HostTensor* b = find(c, bkey, {N});
+        if (!b) return false;
+        out->b = pk.add_f32(b->data.data(), N);
+    }
+    return true;
+}
+
+bool pack_vec(fvhd_ctx* c, Packer& pk, const std::string& key, std::initializer_list<int64_t> shape, size_t* off)
+{
+    const HostTensor* t = find(c, key, shape);
+    if (!t) return false;
+    *off = pk.add_f32(t->data.data(), t->data.size());
+    return true;
+}
+
+// ConvFFN (mci.py:862-927): dw7x7 (no bias) + eval BatchNorm folded into taps/bias, fc1, fc2; layer scale key given
+bool pack_ffn(fvhd_ctx* c, Packer& pk, const std::string& p, const std::string& ls_key, int C, FfnW* out)
+{
+    const HostTensor* g = find(c, p + ".convffn.conv.bn.weight", {C});
+    const HostTensor* be = find(c, p + ".convffn.conv.bn.bias", {C});
+    const HostTensor* mu = find(c, p + ".convffn.conv.bn.running_mean", {C});
+    const HostTensor* var = find(c, p + ".convffn.conv.bn.running_var", {C});
+    if (!g || !be || !mu || !var) return false;
+    // y = (conv - mu) / sqrt(var + eps) * gamma + beta  =>  w' = w * s, b' = beta - mu * s, s = gamma / sqrt(var + eps)
+    std::vector<float> s(C), b(C);
+    for (int i = 0; i < C; ++i) {
+        s[i] = g->data[i] / sqrtf(var->data[i] + kBnEps);
+        b[i] = be->data[i] - mu->data[i] * s[i];
+    }
+    if (!pack_dw(c, pk, p + ".convffn.conv.conv.weight", "", C, 7, &out->dw7, &s, &b)) return false;
+    if (!pack_gemm(c, pk, p + ".convffn.fc1.weight", p + ".convffn.fc1.bias", 4 * C, C, true, &out->fc1)) return false;
+    if (!pack_gemm(c, pk, p + ".convffn.fc2.weight", p + ".convffn.fc2.bias", C, 4 * C, true, &out->fc2)) return false;
+    return pack_vec(c, pk, ls_key, {C, 1, 1}, &out->ls);
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Ws {   // workspace carve-up for batch B
+    char *X, *T, *A, *H, *tok, *ph, *cast;
+    float *pooled, *scale;
+    size_t total;
+};
+
+Ws carve(const fvhd_ctx* c, char* base, int B, int hidden)
+{
+    const size_t unit = (size_t)(c->R / 4) * (c->R / 4) * 96 * 2 * B;   // bytes of one stage-0 activation (bf16)
+    const size_t Tn = (size_t)(c->R / 64) * (c->R / 64);
+    Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    w.X = take(unit);
+    w.T = take(unit);
+    w.A = take(unit);
+    w.H = take(4 * unit);
+    w.tok = take(Tn * B * kOutDim * 2);
+    w.ph = take(Tn * B * (size_t)(hidden > 0 ? hidden : 1) * 2);
+    w.cast = take(Tn * B * kOutDim * 2);
+    w.pooled = (float*)take((size_t)B * kOutDim * 4);
+    w.scale = (float*)take((size_t)B * kOutDim * 4);
+    w.total = off;
+    return w;
+}
+
+int ensure_ws(fvhd_ctx* c, int B)
+{
+    if (c->ws && B <= c->ws_batch && c->hidden <= c->ws_hidden) return 0;
+    const int nb = B > c->ws_batch ? B : c->ws_batch;
+    const size_t need = carve(c, nullptr, nb, c->hidden).total;
+    hipError_t e = hipDeviceSynchronize();   // growing the arena: make sure nothing still uses the old one
+    if (e != hipSuccess) return hip_fail("hipDeviceSynchronize", e);
+    if (c->ws) (void)hipFree(c->ws);
+    c->ws = nullptr;
+    e = hipMalloc((void**)&c->ws, need);
+    if (e != hipSuccess) return hip_fail("hipMalloc(workspace)", e);
+    c->ws_bytes = need;
+    c->ws_batch = nb;
+    c->ws_hidden = c->hidden;
+    return 0;
+}
+
+hipEvent_t get_event(fvhd_ctx* c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Scope {   // brackets one launch with events when profiling is on
+    fvhd_ctx* c; hipStream_t st; int idx = -1;
+    Scope(fvhd_ctx* c_, hipStream_t st_, int cls) : c(c_), st(st_)
+    {
+        if (!c->prof) return;
+        ProfRec r{cls, get_event(c), get_event(c)};
+        (void)hipEventRecord(r.a, st);
+        c->recs.push_back(r);
+        idx = (int)c->recs.size() - 1;
+    }
+    ~Scope() { if (idx >= 0) (void)hipEventRecord(c->recs[idx].b, st); }
+};
+
+#define CHECK_LAUNCH(expr, what)                                              \
+    do {                                                                      \
+        int _e = (expr);                                                      \
+        if (_e) return hip_fail(what, (hipError_t)_e);                        \
+    } while (0)
+
+int run_dw(fvhd_ctx* c, hipStream_t st, int cls, const DwW& w, const void* x, void* y, int B, int H, int W, int Cin,
+           int stride, int mult, int gelu)
+{
+    Scope s(c, st, cls);
+    CHECK_LAUNCH(fvhd_launch_dwconv(st, x, y, c->wp<float>(w.w), c->wp<float>(w.b), B, H, W, Cin, w.K, stride, mult, gelu),
+                 "dwconv launch");
+    return 0;
+}
+
+int run_gemm(fvhd_ctx* c, hipStream_t st, int cls, const char* wbase, const GemmW& g, const void* A, const float* ls,
+             const void* resid, void* out, int M, int epi, int odt = FVHD_BF16)
+{
+    Scope s(c, st, cls);
+    CHECK_LAUNCH(fvhd_launch_gemm(st, A, wbase + g.w, g.has_bias ? (const float*)(wbase + g.b) : nullptr, ls, resid, out,
+                                  M, g.N, g.K, epi, odt),
+                 "gemm launch");
+    return 0;
+}
+
+// ConvFFN + layer scale + residual, in place on x (mci.py:1106-1109 / 1185-1188 second line)
+int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, int B, int H, int Wd, int C)
+{
+    const int M = B * H * Wd;
+    int e;
+    if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0))) return e;
+    if ((e = run_gemm(c, st, C_FC1, c->wdev, f.fc1, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_BIAS_GELU))) return e;
+    return run_gemm(c, st, C_FC2, c->wdev, f.fc2, w.H, c->wp<float>(f.ls), x, x, M, FVHD_EPI_BIAS_LS_RESID);
+}
+
+int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out, int out_dtype, hipStream_t st)
+{
+    if (!c->finalized) return fail("fvhd_encode: weights not finalized (call fvhd_finalize_weights)");
+    if (B <= 0) return fail("fvhd_encode: batch must be positive");
+    if (img_dtype < 0 || img_dtype > 2 || out_dtype < 0 || out_dtype > 2) return fail("fvhd_encode: bad dtype");
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (dev != c->device) {
+        hipError_t he = hipSetDevice(c->device);
+        if (he != hipSuccess) return hip_fail("hipSetDevice", he);
+    }
+    int e = ensure_ws(c, B);
+    if (e) return e;
+    const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
+    const Model& m = c->m;
+    const int R = c->R;
+    char *X = w.X, *T = w.T;
+
+    // ---- convolutional_stem (mci.py:553-603) ----
+    {
+        Scope s(c, st, C_STEM);
+        CHECK_LAUNCH(fvhd_launch_stem_conv(st, images, img_dtype, w.H, c->wp<float>(m.stem0_w), c->wp<float>(m.stem0_b), B, R),
+                     "stem conv launch");
+    }
+    if ((e = run_dw(c, st, C_STEM, m.stem1, w.H, w.A, B, R / 2, R / 2, 96, 2, 1, 1))) return e;
+    int H = R / 4, C = kDims[0];
+    if ((e = run_gemm(c, st, C_STEM, c->wdev, m.stem2, w.A, nullptr, nullptr, X, B * H * H, FVHD_EPI_BIAS_GELU))) return e;
+
+    // ---- network (mci.py:1431-1434; construction order mci.py:1361-1399) ----
+    for (int sIdx = 0; sIdx < kStages; ++sIdx) {
+        C = kDims[sIdx];
+        const int M = B * H * H;
+        if (sIdx >= 3) {   // RepCPE (mci.py:992-995)
+            if ((e = run_dw(c, st, C_DW7, m.cpe[sIdx - 3], X, T, B, H, H, C, 1, 1, 0))) return e;
+            std::swap(X, T);
+        }
+        if (sIdx < 3) {
+            for (const RepBlockW& blk : m.rep[sIdx]) {                       // RepMixerBlock (mci.py:1106-1109)
+                if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0))) return e;
+                std::swap(X, T);
+                if ((e = run_ffn(c, st, blk.ffn, w, X, B, H, H, C))) return e;
+            }
+        } else {
+            for (const AttnBlockW& blk : m.att[sIdx - 3]) {                  // AttentionBlock (mci.py:1185-1188)
+                {
+                    Scope s(c, st, C_LN);
+                    CHECK_LAUNCH(fvhd_launch_layernorm(st, X, w.A, c->wp<float>(blk.ln_w), c->wp<float>(blk.ln_b), M, C, kLnEps),
+                                 "layernorm launch");
+                }
+                if ((e = run_gemm(c, st, C_QKV, c->wdev, blk.qkv, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_NONE))) return e;
+                {
+                    Scope s(c, st, C_ATT);
+                    CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C), "attention launch");
+                }
+                if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID))) return e;
+                if ((e = run_ffn(c, st, blk.ffn, w, X, B, H, H, C))) return e;
+            }
+        }
+        if (sIdx < kStages - 1) {   // PatchEmbed (mci.py:739-741)
+            const DownW& d = m.down[sIdx];
+            if ((e = run_dw(c, st, C_DWDOWN, d.dw, X, T, B, H, H, C, 2, 2, 1))) return e;
+            H /= 2;
+            if ((e = run_gemm(c, st, C_1X1, c->wdev, d.pw, T, nullptr, nullptr, X, B * H * H, FVHD_EPI_BIAS_GELU))) return e;
+        }
+    }
+
+    // ---- conv_exp (mci.py:1401-1411, 1444) + feature_select (mobileclip_encoder.py:60-68) ----
+    if ((e = run_dw(c, st, C_HEAD, m.conv_exp, X, T, B, H, H, kDims[4], 1, 2, 0))) return e;
+    {
+        Scope s(c, st, C_HEAD);
+        CHECK_LAUNCH(fvhd_launch_se_head(st, T, w.pooled, w.scale, c->wp<float>(m.se_wr), c->wp<float>(m.se_br),
+                                         c->wp<float>(m.se_we), c->wp<float>(m.se_be), out, out_dtype, B, H * H, kOutDim, kSeRd),
+                     "se head launch");
+    }
+    return 0;
+}
+
+int project_impl(fvhd_ctx* c, const void* tokens, int in_dtype, int rows, void* out, int out_dtype, hipStream_t st,
+                 const Ws& w)
+{
+    const void* a = tokens;
+    if (in_dtype != FVHD_BF16) {
+        Scope s(c, st, C_PROJECTOR);
+        CHECK_LAUNCH(fvhd_launch_cast_to_bf16(st, tokens, in_dtype, w.cast, (long)rows * c->mm_hidden), "cast launch");
+        a = w.cast;
+    }
+    int e;
+    if ((e = run_gemm(c, st, C_PROJECTOR, c->pdev, c->p0, a, nullptr, nullptr, w.ph, rows, FVHD_EPI_BIAS_GELU))) return e;
+    return run_gemm(c, st, C_PROJECTOR, c->pdev, c->p2, w.ph, nullptr, nullptr, out, rows, FVHD_EPI_BIAS, out_dtype);
+}
+
+}  // namespace
+
+// ===================================================================================================
+extern "C" {
+
+int fvhd_version(void) { return 100; }
+
+const char* fvhd_last_error(void) { return g_err.c_str(); }
+
+int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
+{
+    if (!out) return fail("fvhd_create: out is NULL");
+    *out = nullptr;
+    if (image_size <= 0 || image_size % 64) return fail("fvhd_create: image_size must be a positive multiple of 64");
+    if (max_batch <= 0) return fail("fvhd_create: max_batch must be positive");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail("fvhd_create: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail("fvhd_create: bad device index");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    fvhd_ctx* c = new fvhd_ctx();
+    c->device = device;
+    c->R = image_size;
+    c->max_batch = max_batch;
+    *out = c;
+    return 0;
+}
+
+void fvhd_destroy(fvhd_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& ev : c->ev_pool) (void)hipEventDestroy(ev);
+    if (c->wdev) (void)hipFree(c->wdev);
+    if (c->pdev) (void)hipFree(c->pdev);
+    if (c->ws) (void)hipFree(c->ws);
+    delete c;
+}
+
+int fvhd_set_tensor(fvhd_ctx* c, const char* key, const float* host_data, const int64_t* shape, int ndim)
+{
+    if (!c || !key || !host_data || ndim < 0 || ndim > 8) return fail("fvhd_set_tensor: bad argument");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + n);
+    c->raw[key] = std::move(t);
+    c->finalized = false;
+    return 0;
+}
+
+int fvhd_finalize_weights(fvhd_ctx* c)
+{
+    if (!c) return fail("fvhd_finalize_weights: ctx is NULL");
+    Packer pk;
+    Model m;
+    // ---- stem ----
+    {
+        const HostTensor* w = find(c, "patch_embed.0.reparam_conv.weight", {96, 3, 3, 3});
+        const HostTensor* b = find(c, "patch_embed.0.reparam_conv.bias", {96});
+        if (!w || !b) return 1;
+        std::vector<float> t(27 * 96);
+        for (int oc = 0; oc < 96; ++oc)
+            for (int k = 0; k < 27; ++k) t[(size_t)k * 96 + oc] = w->data[(size_t)oc * 27 + k];   // k = ci*9 + ky*3 + kx
+        m.stem0_w = pk.add_f32(t.data(), t.size());
+        m.stem0_b = pk.add_f32(b->data.data(), 96);
+    }
+    if (!pack_dw(c, pk, "patch_embed.1.reparam_conv.weight", "patch_embed.1.reparam_conv.bias", 96, 3, &m.stem1)) return 1;
+    if (!pack_gemm(c, pk, "patch_embed.2.reparam_conv.weight", "patch_embed.2.reparam_conv.bias", 96, 96, true, &m.stem2)) return 1;
+    // ---- network entries in construction order (mci.py:1361-1399) ----
+    int idx = 0;
+    for (int s = 0; s < kStages; ++s) {
+        const int C = kDims[s];
+        if (s >= 3) {
+            const std::string p = "network." + std::to_string(idx++);
+            if (!pack_dw(c, pk, p + ".reparam_conv.weight", p + ".reparam_conv.bias", C, 7, &m.cpe[s - 3])) return 1;
+        }
+        const std::string ps = "network." + std::to_string(idx++);
+        for (int b = 0; b < kLayers[s]; ++b) {
+            const std::string p = ps + "." + std::to_string(b);
+            if (s < 3) {
+                RepBlockW blk;
+                if (!pack_dw(c, pk, p + ".token_mixer.reparam_conv.weight", p + ".token_mixer.reparam_conv.bias", C, 3, &blk.mixer)) return 1;
+                if (!pack_ffn(c, pk, p, p + ".layer_scale", C, &blk.ffn)) return 1;
+                m.rep[s].push_back(blk);
+            } else {
+                AttnBlockW blk;
+                if (!pack_vec(c, pk, p + ".norm.weight", {C}, &blk.ln_w)) return 1;
+                if (!pack_vec(c, pk, p + ".norm.bias", {C}, &blk.ln_b)) return 1;
+                if (!pack_vec(c, pk, p + ".layer_scale_1", {C, 1, 1}, &blk.ls1)) return 1;
+                if (!pack_gemm(c, pk, p + ".token_mixer.qkv.weight", "", 3 * C, C, false, &blk.qkv)) return 1;
+                if (!pack_gemm(c, pk, p + ".token_mixer.proj.weight", p + ".token_mixer.proj.bias", C, C, false, &blk.proj)) return 1;
+                if (!pack_ffn(c, pk, p, p + ".layer_scale_2", C, &blk.ffn)) return 1;
+                m.att[s - 3].push_back(blk);
+            }
+        }
+        if (s < kStages - 1) {
+            const std::string p = "network." + std::to_string(idx++);
+            const int C2 = kDims[s + 1];
+            if (!pack_dw(c, pk, p + ".proj.0.lkb_reparam.weight", p + ".proj.0.lkb_reparam.bias", C2, 7, &m.down[s].dw)) return 1;
+            if (!pack_gemm(c, pk, p + ".proj.1.reparam_conv.weight", p + ".proj.1.reparam_conv.bias", C2, C2, true, &m.down[s].pw)) return 1;
+        }
+    }
+    // ---- conv_exp + SE ----
+    if (!pack_dw(c, pk, "conv_exp.reparam_conv.weight", "conv_exp.reparam_conv.bias", kOutDim, 3, &m.conv_exp)) return 1;
+    if (!pack_vec(c, pk, "conv_exp.se.reduce.weight", {kSeRd, kOutDim, 1, 1}, &m.se_wr)) return 1;
+    if (!pack_vec(c, pk, "conv_exp.se.reduce.bias", {kSeRd}, &m.se_br)) return 1;
+    if (!pack_vec(c, pk, "conv_exp.se.expand.weight", {kOutDim, kSeRd, 1, 1}, &m.se_we)) return 1;
+    if (!pack_vec(c, pk, "conv_exp.se.expand.bias", {kOutDim}, &m.se_be)) return 1;
+    // head.proj (GlobalPool2D, mci.py:1290-1302) is dead on this path: feature_select drops the logits.
+
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    (void)hipDeviceSynchronize();
+    if (c->wdev) (void)hipFree(c->wdev);
+    c->wdev = nullptr;
+    e = hipMalloc((void**)&c->wdev, pk.buf.size());
+    if (e != hipSuccess) return hip_fail("hipMalloc(weights)", e);
+    e = hipMemcpy(c->wdev, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail("hipMemcpy(weights)", e);
+    c->m = m;
+    c->finalized = true;
+    c->raw.clear();   // the packed image is the only copy the library keeps
+    return ensure_ws(c, c->max_batch);
+}
+
+int fvhd_set_projector(fvhd_ctx* c, const float* w0, const float* b0, const float* w2, const float* b2, int mm_hidden, int hidden)
+{
+    if (!c || !w0 || !b0 || !w2 || !b2) return fail("fvhd_set_projector: bad argument");
+    if (mm_hidden % 32 || hidden % 32) return fail("fvhd_set_projector: mm_hidden and hidden must be multiples of 32");
+    Packer pk;
+    GemmW p0, p2;
+    p0.w = pk.add_bf16(w0, (size_t)hidden * mm_hidden); p0.b = pk.add_f32(b0, hidden); p0.N = hidden; p0.K = mm_hidden; p0.has_bias = true;
+    p2.w = pk.add_bf16(w2, (size_t)hidden * hidden); p2.b = pk.add_f32(b2, hidden); p2.N = hidden; p2.K = hidden; p2.has_bias = true;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    (void)hipDeviceSynchronize();
+    if (c->pdev) (void)hipFree(c->pdev);
+    c->pdev = nullptr;
+    e = hipMalloc((void**)&c->pdev, pk.buf.size());
+    if (e != hipSuccess) return hip_fail("hipMalloc(projector)", e);
+    e = hipMemcpy(c->pdev, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail("hipMemcpy(projector)", e);
+    c->p0 = p0; c->p2 = p2; c->mm_hidden = mm_hidden; c->hidden = hidden;
+    return ensure_ws(c, c->ws_batch > 0 ? c->ws_batch : c->max_batch);
+}
+
+int fvhd_encode(fvhd_ctx* c, const void* images, int img_dtype, int batch, void* tokens_out, int out_dtype, fvhd_stream_t stream)
+{
+    if (!c || !images || !tokens_out) return fail("fvhd_encode: NULL argument");
+    return encode_impl(c, images, img_dtype, batch, tokens_out, out_dtype, (hipStream_t)stream);
+}
+
+int fvhd_project(fvhd_ctx* c, const void* tokens, int in_dtype, int rows, void* out, int out_dtype, fvhd_stream_t stream)
+{
+    if (!c || !tokens || !out) return fail("fvhd_project: NULL argument");
+    if (!c->pdev) return fail("fvhd_project: projector weights not set (call fvhd_set_projector)");
+    if (rows <= 0) return fail("fvhd_project: rows must be positive");
+    const int Tn = fvhd_num_tokens(c);
+    int e = ensure_ws(c, (rows + Tn - 1) / Tn);
+    if (e) return e;
+    const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
+    return project_impl(c, tokens, in_dtype, rows, out, out_dtype, (hipStream_t)stream, w);
+}
+
+int fvhd_encode_images(fvhd_ctx* c, const void* images, int img_dtype, int batch, void* out, int out_dtype, fvhd_stream_t stream)
+{
+    if (!c || !images || !out) return fail("fvhd_encode_images: NULL argument");
+    if (!c->pdev) return fail("fvhd_encode_images: projector weights not set (call fvhd_set_projector)");
+    int e = ensure_ws(c, batch);
+    if (e) return e;
+    const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
+    e = encode_impl(c, images, img_dtype, batch, w.tok, FVHD_BF16, (hipStream_t)stream);
+    if (e) return e;
+    return project_impl(c, w.tok, FVHD_BF16, batch * fvhd_num_tokens(c), out, out_dtype, (hipStream_t)stream, w);
+}
+
+int fvhd_num_tokens(const fvhd_ctx* c) { return c ? (c->R / 64) * (c->R / 64) : 0; }
+int fvhd_hidden_size(const fvhd_ctx* c) { (void)c; return kOutDim; }
+
+int fvhd_profile_enable(fvhd_ctx* c, int on)
+{
+    if (!c) return fail("fvhd_profile_enable: ctx is NULL");
+    c->prof = on != 0;
+    return 0;
+}
+
+static int drain(fvhd_ctx* c)
+{
+    for (auto& r : c->recs) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return hip_fail("hipEventSynchronize", e);
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return hip_fail("hipEventElapsedTime", e);
+        c->acc_ms[r.cls] += ms;
+        c->acc_n[r.cls] += 1;
+        c->ev_pool.push_back(r.a);
+        c->ev_pool.push_back(r.b);
+    }
+    c->recs.clear();
+    return 0;
+}
+
+int fvhd_profile_reset(fvhd_ctx* c)
+{
+    if (!c) return fail("fvhd_profile_reset: ctx is NULL");
+    int e = drain(c);
+    for (int i = 0; i < C_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
+    return e;
+}
+
+int fvhd_profile_read(fvhd_ctx* c, int max_classes, const char** names, double* ms, int64_t* launches, int* n_classes)
+{
+    if (!c || !names || !ms || !launches || !n_classes) return fail("fvhd_profile_read: NULL argument");
+    int e = drain(c);
+    if (e) return e;
+    int n = C_COUNT < max_classes ? C_COUNT : max_classes;
+    for (int i = 0; i < n; ++i) { names[i] = kClassNames[i]; ms[i] = c->acc_ms[i]; launches[i] = c->acc_n[i]; }
+    *n_classes = n;
+    return 0;
+}
+
+// ---- single-op entry points -------------------------------------------------------------------------
+int fvhd_op_dwconv(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int Cin,
+                   int K, int stride, int mult, int gelu)
+{
+    int e = fvhd_launch_dwconv((hipStream_t)st, x, y, w, bias, B, H, W, Cin, K, stride, mult, gelu);
+    return e ? hip_fail("fvhd_op_dwconv", (hipError_t)e) : 0;
+}
+
+int fvhd_op_gemm(fvhd_stream_t st, const void* A, const void* Wt, const float* bias, const float* ls, const void* resid,
+                 void* out, int M, int N, int K, int epilogue, int out_dtype)
+{
+    int e = fvhd_launch_gemm((hipStream_t)st, A, Wt, bias, ls, resid, out, M, N, K, epilogue, out_dtype);
+    return e ? hip_fail("fvhd_op_gemm", (hipError_t)e) : 0;
+}
+
+int fvhd_op_layernorm(fvhd_stream_t st, const void* x, void* y, const float* w, const float* b, int M, int C, float eps)
+{
+    int e = fvhd_launch_layernorm((hipStream_t)st, x, y, w, b, M, C, eps);
+    return e ? hip_fail("fvhd_op_layernorm", (hipError_t)e) : 0;
+}
+
+int fvhd_op_attention(fvhd_stream_t st, const void* qkv, void* out, int B, int N, int C)
+{
+    int e = fvhd_launch_attention((hipStream_t)st, qkv, out, B, N, C);
+    return e ? hip_fail("fvhd_op_attention", (hipError_t)e) : 0;
+}
+
+int fvhd_op_stem_conv(fvhd_stream_t st, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R)
+{
+    int e = fvhd_launch_stem_conv((hipStream_t)st, img, dtype, out, w, bias, B, R);
+    return e ? hip_fail("fvhd_op_stem_conv", (hipError_t)e) : 0;
+}
+
+int fvhd_op_se_head(fvhd_stream_t st, const void* y, float* pooled, float* scale, const float* wr, const float* br,
+                    const float* we, const float* be, void* out, int out_dtype, int B, int T, int C, int RD)
+{
+    int e = fvhd_launch_se_head((hipStream_t)st, y, pooled, scale, wr, br, we, be, out, out_dtype, B, T, C, RD);
+    return e ? hip_fail("fvhd_op_se_head", (hipError_t)e) : 0;
+}
+
+}  // extern "C"

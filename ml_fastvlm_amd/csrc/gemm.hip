@@ -1,0 +1,199 @@
+// bf16 MFMA GEMM with fused epilogues:  out[M,N] = epi(A[M,K] . Wt[N,K]^T)
+//
+// Every 1x1 convolution / nn.Linear of the encode_images() path is this op once activations are NHWC
+// (a 1x1 conv over [B,H,W,C] is a row-major GEMM over M = B*H*W rows); PyTorch stores both
+// nn.Linear.weight and Conv2d(k=1).weight as [out, in] = [N, K] with K contiguous, which is exactly
+// the "B^T" operand layout an MFMA wants, so weights are used as stored.
+//   ConvFFN.fc1 + GELU, ConvFFN.fc2 (+ layer_scale * . + residual)      mci.py:908-910, 922-926, 1106-1109, 1185-1188
+//   stem[2] / PatchEmbed.proj[1] 1x1 + GELU                             mci.py:587-598, 722-734
+//   MHSA.qkv (no bias), MHSA.proj (+ layer_scale_1 * . + residual)      mci.py:656-658, 668, 681
+//   mm_projector Linear/GELU/Linear                                     multimodal_projector/builder.py:23-30
+//
+// gfx950 design (v1: LDS-staged, register-prefetched, 4 waves, 16x16x32 bf16 MFMA):
+//   * 128 x (96|128) output tile per 256-thread workgroup, waves 2(M) x 2(N); each wave owns 4 x NF
+//     16x16 fragments, fp32 accumulators (64 or 48 VGPRs).
+//   * operands are staged global -> VGPR (16 B/lane, coalesced: 8 or 4 lanes per 128/64-B row)
+//     -> LDS with an XOR swizzle on the 16-B slot index that makes both the ds_write_b128 (8-lane
+//     groups) and the fragment ds_read_b128 (the 4 non-contiguous 16-lane groups of MI355X_MICROARCH
+//     "LDS") conflict-free; the next K-tile's global loads are issued before the MFMA block of the
+//     current one.
+//   * MFMA is issued "swapped": D = Wfrag x Afrag^T, so a lane ends up holding 4 *consecutive output
+//     columns* of one output row (C/D layout: col = lane&15 -> m, row = 4*(lane>>4)+reg -> n).
+//     bias / layer-scale are then float4 loads, the residual and the store are 8-B bf16x4 accesses,
+//     and bias+GELU / bias+layer_scale+residual run in fp32 on the accumulators (one rounding, on store).
+//   * block ids are remapped so each XCD's private L2 sees a contiguous range of tiles (n fastest):
+//     the N/BN tiles that share an A panel run back-to-back on the same L2.
+#include "fvhd_common.h"
+
+#define EPI_NONE 0
+#define EPI_BIAS 1
+#define EPI_BIAS_GELU 2
+#define EPI_BIAS_LS_RESID 3
+
+template <int BK>
+FVHD_DEV int lds_off(int row, int ks)
+{
+    if constexpr (BK == 64) return row * 128 + ((ks ^ ((row >> 1) & 7)) << 4);
+    else return row * 64 + ((ks ^ ((0 - (row >> 2)) & 3)) << 4);
+}
+
+template <int NF, int BK, int EPI, int ODT>
+__global__ __launch_bounds__(256) void gemm_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ ls, const bf16* resid, void* out, int M, int N, int K, int tiles_n, int nwg)
+{
+    constexpr int BM = 128, BN = 32 * NF, MF = 4;
+    constexpr int ROWB = BK * 2;
+    constexpr int CPR = BK / 8;                       // 16-B chunks per tile row
+    constexpr int A_CH = BM * CPR / 256;
+    constexpr int W_CH = (BN * CPR + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * ROWB];
+    char* ldsA = lds;
+    char* ldsW = lds + BM * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, g = lane >> 4;
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int tm = L / tiles_n, tn = L - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    u32x4 ra[A_CH], rw[W_CH];
+    const bf16* a_src[A_CH];
+    const bf16* w_src[W_CH];
+    int a_dst[A_CH], w_dst[W_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int idx = i * 256 + tid, row = idx / CPR, ks = idx % CPR;
+        const int gr = min(m0 + row, M - 1);
+        a_src[i] = A + (size_t)gr * K + ks * 8;
+        a_dst[i] = lds_off<BK>(row, ks);
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+        const int idx = i * 256 + tid, row = min(idx / CPR, BN - 1), ks = idx % CPR;
+        const int gr = min(n0 + row, N - 1);
+        w_src[i] = Wt + (size_t)gr * K + ks * 8;
+        w_dst[i] = (idx < BN * CPR) ? lds_off<BK>(row, ks) : -1;
+    }
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i]);
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i]);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) __syncthreads();                 // previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *(u32x4*)(ldsA + a_dst[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i)
+            if (w_dst[i] >= 0) *(u32x4*)(ldsW + w_dst[i]) = rw[i];
+        __syncthreads();
+        if (kt + 1 < nk) {                           // prefetch next K tile while computing this one
+            const int ko = (kt + 1) * BK;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + ko);
+#pragma unroll
+            for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i] + ko);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[MF], wf[NF];
+            const int ks = kk * 4 + g;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(ldsA + lds_off<BK>(wm * 64 + i * 16 + lr, ks));
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const bf16x8*)(ldsW + lds_off<BK>(wn * 16 * NF + j * 16 + lr, ks));
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds out[m][n .. n+3], m = ..+lr, n = ..+4*g -------------------------------
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = n0 + wn * 16 * NF + j * 16 + g * 4;
+        if (n >= N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, lv = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (EPI != EPI_NONE) bv = *(const f32x4*)(bias + n);
+        if constexpr (EPI == EPI_BIAS_LS_RESID) lv = *(const f32x4*)(ls + n);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + lr;
+            if (m >= M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+            }
+            const size_t o = (size_t)m * N + n;
+            if constexpr (EPI == EPI_BIAS_LS_RESID) {
+                const f32x4 r = bf4_to_f32(*(const bf16x4*)(resid + o));
+                v = r + lv * v;
+            }
+            if constexpr (ODT == FVHD_BF16) *(bf16x4*)((bf16*)out + o) = f32_to_bf4(v);
+            else if constexpr (ODT == FVHD_F16) *(f16x4*)((_Float16*)out + o) = __builtin_convertvector(v, f16x4);
+            else *(f32x4*)((float*)out + o) = v;
+        }
+    }
+}
+
+template <int NF, int BK, int EPI, int ODT>
+static hipError_t launch_gemm(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
+                              const bf16* resid, void* out, int M, int N, int K)
+{
+    constexpr int BM = 128, BN = 32 * NF;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_kernel<NF, BK, EPI, ODT>), dim3(nwg), dim3(256), 0, st,
+                       A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+    return hipGetLastError();
+}
+
+template <int NF, int BK>
+static hipError_t dispatch_epi(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
+                               const bf16* resid, void* out, int M, int N, int K, int epi, int odt)
+{
+    if (odt == FVHD_BF16) {
+        switch (epi) {
+        case EPI_NONE: return launch_gemm<NF, BK, EPI_NONE, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
+        case EPI_BIAS: return launch_gemm<NF, BK, EPI_BIAS, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
+        case EPI_BIAS_GELU: return launch_gemm<NF, BK, EPI_BIAS_GELU, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
+        case EPI_BIAS_LS_RESID: return launch_gemm<NF, BK, EPI_BIAS_LS_RESID, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
+        }
+    } else if (epi == EPI_BIAS) {
+        if (odt == FVHD_F16) return launch_gemm<NF, BK, EPI_BIAS, FVHD_F16>(st, A, Wt, bias, ls, resid, out, M, N, K);
+        if (odt == FVHD_F32) return launch_gemm<NF, BK, EPI_BIAS, FVHD_F32>(st, A, Wt, bias, ls, resid, out, M, N, K);
+    }
+    return hipErrorInvalidValue;
+}
+
+// A [M,K] bf16, Wt [N,K] bf16, bias/ls fp32 [N], resid bf16 [M,N] (may alias out), out [M,N] of out_dtype.
+// Requirements: K % 32 == 0, N % 16 == 0.  Non-bf16 outputs only with epi == EPI_BIAS.
+extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, const float* bias, const float* ls,
+                                const void* resid, void* out, int M, int N, int K, int epi, int out_dtype)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 32) || (N % 16)) return (int)hipErrorInvalidValue;
+    const bf16* a = (const bf16*)A;
+    const bf16* w = (const bf16*)Wt;
+    const bf16* r = (const bf16*)resid;
+    const bool nf3 = (N % 128 != 0) && (N % 96 == 0);
+    const bool bk64 = (K % 64 == 0);
+    hipError_t e;
+    if (nf3) e = bk64 ? dispatch_epi<3, 64>(st, a, w, bias, ls, r, out, M, N, K, epi, out_dtype)
+                      : dispatch_epi<3, 32>(st, a, w, bias, ls, r, out, M, N, K, epi, out_dtype);
+    else     e = bk64 ? dispatch_epi<4, 64>(st, a, w, bias, ls, r, out, M, N, K, epi, out_dtype)
+                      : dispatch_epi<4, 32>(st, a, w, bias, ls, r, out, M, N, K, epi, out_dtype);
+    return (int)e;
+}

@@ -1,0 +1,68 @@
+"""Data-parallel encode over the GPUs of one node: one process per GPU, images sharded on the
+batch axis, ONE all-gather of visual tokens at the projector boundary (RCCL over xGMI when the
+process group's backend is "nccl"; the same code runs over gloo on CPU in the tests).
+
+The reference has no collective on this path: images are independent through the
+whole encoder and projector (eval-mode BatchNorm `mci.py:901-907`, per-pixel LayerNorm
+`mci.py:617-623`, per-image attention `mci.py:661-685`; a list of images is a loop of B=1 calls,
+`mobileclip_encoder.py:78-83`), so sharding needs no communication inside the path.  The gather
+exists only because the consumer (the LLM prefill, `llava_arch.py:146-332`) wants every image's
+tokens.
+
+xGMI is point-to-point (7 links per GPU), so the gather is issued as a single
+`all_gather_into_tensor` of each rank's whole shard (12.6 MB for 8 images x 256 x 3072 bf16) -
+one large message per peer, never per-image messages.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of n items: the first n % world ranks get one extra."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_images(images: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = None) -> torch.Tensor:
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    lo, hi = shard_bounds(images.shape[0], rank, world)
+    return images[lo:hi]
+
+
+def all_gather_tokens(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
+    """local [b_r, T, H] on each rank (b_r from `shard_bounds`) -> [global_batch, T, H] on every rank,
+    in image order.  Equal shards take the single-message path; ragged shards are padded to the
+    largest shard for the collective and trimmed afterwards."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = [shard_bounds(global_batch, r, world) for r in range(world)]
+    counts = [hi - lo for lo, hi in sizes]
+    bmax = max(counts)
+    tail = tuple(local.shape[1:])
+    if min(counts) == bmax:
+        out = torch.empty((global_batch,) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    padded = torch.zeros((bmax,) + tail, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    buf = torch.empty((world * bmax,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    return torch.cat([buf[r * bmax: r * bmax + counts[r]] for r in range(world)], 0)
+
+
+def encode_images_data_parallel(encode_fn: Callable[[torch.Tensor], torch.Tensor], images_local: torch.Tensor,
+                                global_batch: int, group=None, gather: bool = True) -> torch.Tensor:
+    """`encode_fn` is this rank's encode_images (tower -> projector) on its own shard.  With
+    `gather=False` the rank-local tokens are returned (throughput benchmarking of the shardable
+    part); with `gather=True` every rank gets all `global_batch` images' tokens."""
+    local = encode_fn(images_local)
+    if not gather:
+        return local
+    return all_gather_tokens(local, global_batch, group=group)

@@ -1,0 +1,240 @@
+"""MI355X drop-in for the reference's `MobileCLIPVisionTower`
+(`llava/model/multimodal_encoder/mobileclip_encoder.py:13-116`).
+
+Same constructor, methods, properties, state-dict key names, input/output shapes and error
+behaviour; the forward pass runs the hand-written gfx950 kernels of `libfvhd.so` through the C ABI
+of `include/fvhd.h` instead of `torch.nn` modules.  There is no CPU path: calling `forward` with
+the parameters on a non-HIP device raises.
+
+Differences that are deliberate and documented in DESIGN.md:
+* arithmetic is bf16 activations / fp32 accumulation whatever `self.dtype` is (the tier's metric
+  dtype); `self.dtype` still reports the parameters' dtype and the output is cast to
+  `images.dtype` exactly as the reference does (`mobileclip_encoder.py:85-86`);
+* inference only: `unfreeze_mm_vision_tower` (training through the tower,
+  `mobileclip_encoder.py:70-75`) raises `NotImplementedError` when gradients are enabled.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import fastvithd_spec as spec
+
+# mobileclip/configs/mobileclip_l.json, image side only (the text tower is not on this path)
+_MODEL_CONFIGS = {
+    "mobileclip_l": {
+        "embed_dim": spec.PROJECTION_DIM,
+        "image_cfg": {"image_size": 1024, "model_name": "fastvithd", "embed_dim": spec.OUT_DIM,
+                      "patch_size": spec.PATCH_SIZE},
+    },
+}
+
+
+def load_model_config(model_name: str) -> Dict:
+    """Mirror of `mobileclip.load_model_config` (`mobileclip/__init__.py:15-31`): the suffix after
+    the second underscore-separated field is stripped; unknown names raise ValueError."""
+    base = "_".join(model_name.split("_")[0:2])
+    if base not in _MODEL_CONFIGS:
+        raise ValueError(f"Unsupported model name: {base}")
+    return copy.deepcopy(_MODEL_CONFIGS[base])
+
+
+class _ParamTree(nn.Module):
+    """A bare container: holds parameters/buffers/children under the reference's names."""
+
+
+def _build_param_tree(root: nn.Module) -> None:
+    for key, (shape, kind) in spec.param_spec().items():
+        parts = key.split(".")
+        mod = root
+        for name in parts[:-1]:
+            child = mod._modules.get(name)
+            if child is None:
+                child = _ParamTree()
+                mod.add_module(name, child)
+            mod = child
+        leaf = parts[-1]
+        if kind == "param":
+            mod.register_parameter(leaf, nn.Parameter(torch.zeros(shape), requires_grad=False))
+        elif kind == "buffer":
+            mod.register_buffer(leaf, torch.ones(shape) if leaf == "running_var" else torch.zeros(shape))
+        else:
+            mod.register_buffer(leaf, torch.zeros(shape, dtype=torch.int64))
+
+
+class FastViTHDWeights(nn.Module):
+    """Stands where the reference has `MCi` (`mobileclip/__init__.py:34-58`): a child called
+    `model` whose state-dict keys are FastViT's (`patch_embed.0.reparam_conv.weight`, ...)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.model = _ParamTree()
+        _build_param_tree(self.model)
+        self._reset_parameters()
+
+    def _reset_parameters(self) -> None:
+        # Deterministic, non-degenerate values so that an un-loaded tower is still a valid
+        # (if meaningless) encoder; real use goes through load_state_dict.
+        from . import synth
+        sd = synth.synthetic_state_dict(seed=0)
+        self.model.load_state_dict(sd, strict=True)
+
+
+class MobileCLIPVisionTower(nn.Module):
+    def __init__(self, vision_tower: str, args, delay_load: bool = False):
+        super().__init__()
+        self.is_loaded = False
+        self.vision_tower_name = vision_tower
+        self.tune_vision_tower = getattr(args, "unfreeze_mm_vision_tower", False)
+        self.input_image_size = int(vision_tower.split("_")[-1])
+        self._ctx: Optional[_lib.Context] = None
+        self._ctx_key = None
+        self._dirty = True
+        self._projector_src = None
+
+        if not delay_load:
+            self.load_model()
+        elif getattr(args, "unfreeze_mm_vision_tower", False):
+            self.load_model()
+        else:
+            self.cfg_only = load_model_config(self.vision_tower_name)
+
+    # ---- construction ------------------------------------------------------------------------------
+    def load_model(self, device_map=None):
+        if self.is_loaded:
+            print("{} is already loaded, `load_model` called again, skipping.".format(self.vision_tower_name))
+            return
+        model_cfg = load_model_config(self.vision_tower_name)
+        model_cfg["image_cfg"]["image_size"] = self.input_image_size      # mobileclip_encoder.py:40
+        if self.input_image_size % spec.PATCH_SIZE:
+            raise ValueError(f"image size {self.input_image_size} is not a multiple of {spec.PATCH_SIZE}")
+        self.cfg_only = model_cfg
+
+        from transformers import CLIPImageProcessor                       # mobileclip_encoder.py:45-49
+        r = model_cfg["image_cfg"]["image_size"]
+        self.image_processor = CLIPImageProcessor(crop_size={"height": r, "width": r},
+                                                  image_mean=[0.0, 0.0, 0.0], image_std=[1.0, 1.0, 1.0],
+                                                  size={"shortest_edge": r})
+        self.vision_tower = FastViTHDWeights()
+        self.vision_tower.requires_grad_(bool(self.tune_vision_tower))
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
+        self.is_loaded = True
+        self._dirty = True
+
+    def _mark_dirty(self) -> None:
+        self._dirty = True
+
+    def _apply(self, fn, *a, **kw):
+        # .to() / .half() / .cuda(): parameter storage (and possibly values, through a dtype cast) changes
+        self._dirty = True
+        return super()._apply(fn, *a, **kw)
+
+    # ---- weights -> library ------------------------------------------------------------------------
+    def _context(self) -> "_lib.Context":
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                f"MobileCLIPVisionTower (MI355X): parameters are on {dev}; this tower has no CPU path - "
+                "move the model to a HIP device (`.to('cuda')`).")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = (idx, self.input_image_size)
+        if self._ctx is None or self._ctx_key != key:
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = _lib.Context(idx, self.input_image_size, max_batch=1)
+            self._ctx_key = key
+            self._dirty = True
+            self._projector_src = None
+        if self._dirty:
+            for k, v in self.vision_tower.model.state_dict().items():
+                if v.is_floating_point():
+                    self._ctx.set_tensor(k, v)
+            self._ctx.finalize()
+            self._dirty = False
+        return self._ctx
+
+    def sync_weights(self) -> None:
+        """Force a re-pack (e.g. after in-place edits of parameters that no hook can see)."""
+        self._dirty = True
+        self._context()
+
+    # ---- forward (mobileclip_encoder.py:70-88) -----------------------------------------------------
+    def forward(self, images: Union[torch.Tensor, List[torch.Tensor]]):
+        if self.tune_vision_tower and torch.is_grad_enabled():
+            raise NotImplementedError("the MI355X tower is inference-only (no backward through the HIP kernels)")
+        with torch.no_grad():
+            return self.forward_images(images)
+
+    def _encode(self, images: torch.Tensor) -> torch.Tensor:
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != images.shape[3] \
+                or images.shape[2] != self.input_image_size:
+            raise ValueError(f"expected images of shape [B,3,{self.input_image_size},{self.input_image_size}], "
+                             f"got {tuple(images.shape)}")
+        ctx = self._context()
+        images = images.to(device=self.device).contiguous()
+        if images.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            images = images.float()
+        out = torch.empty((images.shape[0], ctx.num_tokens, self.hidden_size), device=images.device, dtype=images.dtype)
+        ctx.encode(images, out)
+        return out
+
+    def forward_images(self, images):
+        if type(images) is list:
+            if len(images) == 0:
+                return []
+            # the reference loops B=1 calls (mobileclip_encoder.py:78-83); images are independent, so
+            # same-dtype lists are encoded as one batch and split back into [1, T, C] pieces.
+            if all(im.dtype == images[0].dtype for im in images):
+                feats = self._encode(torch.stack([im.to(self.device) for im in images], 0))
+                return [feats[i:i + 1] for i in range(len(images))]
+            return [self._encode(im.unsqueeze(0)) for im in images]
+        return self._encode(images)
+
+    # ---- encode_images = tower -> projector in one library call (llava_arch.py:141-144) -------------
+    def encode_images_with_projector(self, images: torch.Tensor, projector: nn.Module) -> torch.Tensor:
+        with torch.no_grad():
+            ctx = self._context()
+            w0, b0, w2, b2 = projector[0].weight, projector[0].bias, projector[2].weight, projector[2].bias
+            src = tuple((t.data_ptr(), t._version, t.dtype) for t in (w0, b0, w2, b2))
+            if self._projector_src != src:
+                ctx.set_projector(w0, b0, w2, b2)
+                self._projector_src = src
+            images = images.to(device=self.device).contiguous()
+            if images.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+                images = images.float()
+            out = torch.empty((images.shape[0], ctx.num_tokens, w0.shape[0]), device=images.device, dtype=images.dtype)
+            ctx.encode_images(images, out)
+            return out
+
+    # ---- properties (mobileclip_encoder.py:90-116) ---------------------------------------------------
+    @property
+    def dummy_feature(self):
+        return torch.zeros(1, self.hidden_size, device=self.device, dtype=self.dtype)
+
+    @property
+    def dtype(self):
+        return next(self.vision_tower.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.vision_tower.parameters()).device
+
+    @property
+    def config(self):
+        return self.cfg_only
+
+    @property
+    def hidden_size(self):
+        return self.config["image_cfg"]["embed_dim"]
+
+    @property
+    def num_patches_per_side(self):
+        return self.config["image_cfg"]["image_size"] // self.config["image_cfg"]["patch_size"]
+
+    @property
+    def num_patches(self):
+        return (self.config["image_cfg"]["image_size"] // self.config["image_cfg"]["patch_size"]) ** 2
