@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the encode_images() hot path (BASELINE.json metric: images/sec FastViTHD
+encode @1024x1024 bf16).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (FastViTHD tower + mlp2x_gelu projector, H=896 = FastVLM-0.5B)
+over one synthetic batch of 32 images per GPU, already resident in HBM (BASELINE.json configs[1]).
+With N > 1 every rank encodes its own 32 images (weak scaling, no data-path collective inside the
+encoder) and the step ends with the single RCCL all-gather of visual tokens at the projector
+boundary.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      - for the dominant kernel class: algorithmic FLOPs (or bytes) per launch divided by
+                  the average launch duration measured live with HIP events on the launch stream
+                  (fvhd_profile_*), against the dense bf16 MFMA peak / HBM3E peak.
+  cpu_baseline  - the CPU oracle (a port of the reference's PyTorch path; the reference itself is
+                  not present on the GPU box) timed on this host's cores on a bounded sample.
+  kernels       - per-class table from the same profiled pass (ms per step, launches, TF/s or GB/s).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0         # HBM3E spec, same table
+
+
+def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True):
+    """Per kernel class: (FLOPs, HBM bytes) of ONE step at batch B, counted algorithmically
+    (2*MAC; each activation tensor once in + once out per launch, bf16; weights once)."""
+    from ml_fastvlm_amd import fastvithd_spec as spec
+    w = {k: [0.0, 0.0] for k in ("stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv",
+                                 "gemm_proj", "layernorm", "attention", "head", "projector", "ffn_fused")}
+
+    def add(k, flops, bytes_):
+        w[k][0] += flops
+        w[k][1] += bytes_
+
+    def gemm(k, M, N, K, resid=False):
+        add(k, 2.0 * M * N * K, 2.0 * (M * K + M * N * (2 if resid else 1) + N * K))
+
+    H = R // 2
+    add("stem", 2.0 * B * H * H * 96 * 27, B * (3 * R * R * 2 + H * H * 96 * 2))             # dense 3x3 s2
+    add("stem", 2.0 * B * (H // 2) ** 2 * 96 * 9, B * (H * H * 96 * 2 + (H // 2) ** 2 * 96 * 2))  # dw 3x3 s2
+    H //= 2
+    gemm("stem", B * H * H, 96, 96)
+    for s, (C, depth) in enumerate(zip(spec.EMBED_DIMS, spec.LAYERS)):
+        M = B * H * H
+        if spec.HAS_CPE[s]:
+            add("dw7", 2.0 * M * C * 49, 4.0 * M * C)
+        for _ in range(depth):
+            if spec.TOKEN_MIXERS[s] == "repmixer":
+                add("dw3", 2.0 * M * C * 9, 4.0 * M * C)
+            else:
+                add("layernorm", 8.0 * M * C, 4.0 * M * C)
+                gemm("gemm_qkv", M, 3 * C, C)
+                N = H * H
+                add("attention", 4.0 * B * (C // 32) * N * N * 32, 2.0 * (M * 3 * C + M * C))
+                gemm("gemm_proj", M, C, C, resid=True)
+            add("dw7", 2.0 * M * C * 49, 4.0 * M * C)
+            if fused and C <= 384:     # fc1 + GELU + fc2 + layer-scale + residual in one launch, hidden on chip
+                add("ffn_fused", 16.0 * M * C * C, 2.0 * (3 * M * C + 8 * C * C))
+            else:
+                gemm("gemm_fc1", M, 4 * C, C)
+                gemm("gemm_fc2", M, C, 4 * C, resid=True)
+        if s < len(spec.LAYERS) - 1:
+            C2 = spec.EMBED_DIMS[s + 1]
+            add("dw_down", 2.0 * (M // 4) * C2 * 49, 2.0 * (M * C + (M // 4) * C2))
+            H //= 2
+            gemm("gemm_1x1", B * H * H, C2, C2)
+    T = H * H
+    add("head", 2.0 * B * T * 3072 * 9 + 4.0 * B * 3072 * 192, 2.0 * B * T * (1536 + 3 * 3072))
+    gemm("projector", B * T, hidden, 3072)
+    gemm("projector", B * T, hidden, hidden)
+    return {k: tuple(v) for k, v in w.items()}
+
+
+GEMM_CLASSES = {"gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv", "gemm_proj", "attention", "projector", "ffn_fused"}
+
+
+def cpu_baseline(res: int, hidden: int, budget_s: float = 25.0):
+    """Times the CPU oracle (fp32) on B=1 images of the same workload.  The host of a GPU box can
+    expose far more logical CPUs than a oneDNN convolution of this size scales to (256 threads ran
+    100x slower than 8 in round 1), so a few thread counts are tried and the best is reported
+    together with the number of threads it used."""
+    from ml_fastvlm_amd import synth
+    from oracle import fastvithd_oracle as O
+    torch.set_flush_denormal(True)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    sd = synth.synthetic_state_dict(1234)
+    pj = synth.synthetic_projector_state_dict(hidden, 1234)
+    x = synth.synthetic_images(1, res, seed=0)
+    best = None
+    t_start = time.perf_counter()
+    for threads in sorted({min(avail, t) for t in (8, 16, 32, 64, avail)}):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        O.encode_images(x, sd, pj)                   # warm-up for this thread count
+        warm = time.perf_counter() - t0
+        if warm > 8.0:                               # pathological oversubscription: do not burn the budget
+            continue
+        n, t0 = 0, time.perf_counter()
+        while n < 3:
+            O.encode_images(x, sd, pj)
+            n += 1
+        rate = n / (time.perf_counter() - t0)
+        if best is None or rate > best[0]:
+            best = (rate, threads, n)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    if best is None:
+        return {"value": None, "unit": "images/sec", "cores": avail, "kind": "port", "sample": "every thread count exceeded 8 s per image"}
+    return {"value": round(best[0], 4), "unit": "images/sec", "cores": best[1], "kind": "port",
+            "sample": f"{best[2]} x (1 image {res}x{res}, fp32, torch CPU oracle of the reference path, best of thread counts "
+                      f"<= {avail} logical CPUs; {best[1]} threads used)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--hidden", type=int, default=896, help="LLM hidden size of the projector (896 = Qwen2-0.5B)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tower-only", action="store_true", help="time the vision tower without the projector")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import ml_fastvlm_amd as fv
+    from ml_fastvlm_amd import distributed as D
+    from ml_fastvlm_amd import synth
+
+    B, R, Hd = args.batch, args.res, args.hidden
+    tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{R}", SimpleNamespace(unfreeze_mm_vision_tower=False))
+    tower.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234), strict=True)
+    proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=Hd))
+    proj.load_state_dict(synth.synthetic_projector_state_dict(Hd, 1234), strict=True)
+    tower, proj = tower.to(dev, torch.bfloat16), proj.to(dev, torch.bfloat16)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    images = torch.rand((B, 3, R, R), generator=g).to(dev, torch.bfloat16)      # synthetic, in [0,1), HBM-resident
+
+    def step():
+        if args.tower_only:
+            local = tower(images)
+        else:
+            local = fv.encode_images(tower, proj, images)
+        if world > 1:
+            return D.all_gather_tokens(local, B * world)
+        return local
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    result = {
+        "metric": "images/sec FastViTHD encode_images @1024x1024 bf16",
+        "value": round(world * B * args.steps / dt, 2),
+        "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: FastViTHD encoder{'' if args.tower_only else ' + mlp2x_gelu projector (H=%d)' % Hd}, "
+                               f"batch={B}/GPU synthetic {R}x{R} bf16 images in [0,1), seeded synthetic weights, "
+                               f"{'tokens all-gathered over RCCL at the projector boundary' if world > 1 else 'single GPU'}",
+                   "global_batch": B * world, "image_size": R, "tokens_per_image": (R // 64) ** 2, "parallelism": f"dp{world}"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        ctx = tower._context()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        psteps = max(2, min(5, args.steps))
+        for _ in range(psteps):
+            fv.encode_images(tower, proj, images) if not args.tower_only else tower(images)
+        torch.cuda.synchronize()
+        prof = ctx.profile_read()
+        ctx.profile_enable(False)
+        work = algorithmic_work(B, R, Hd, fused=prof.get("ffn_fused", (0, 0))[1] > 0)
+        table, total_ms = {}, 0.0
+        for k, (ms, n) in prof.items():
+            if n == 0:
+                continue
+            ms_step = ms / psteps
+            total_ms += ms_step
+            fl, by = work[k]
+            table[k] = {"ms_per_step": round(ms_step, 3), "launches_per_step": n // psteps,
+                        "tflops": round(fl / ms_step / 1e9, 1), "gbs": round(by / ms_step / 1e6, 1)}
+        dom = max(table, key=lambda k: table[k]["ms_per_step"])
+        n_dom = table[dom]["launches_per_step"]
+        avg_ms = table[dom]["ms_per_step"] / n_dom
+        if dom in GEMM_CLASSES:
+            ach = work[dom][0] / n_dom / (avg_ms * 1e-3) / 1e12
+            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                  "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": work[dom][0] / n_dom}
+        else:
+            ach = work[dom][1] / n_dom / (avg_ms * 1e-3) / 1e9
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": work[dom][1] / n_dom}
+        result["kernels"] = table
+        result["kernel_ms_per_step_profiled"] = round(total_ms, 3)
+        tot_fl = sum(v[0] for v in work.values())
+        result["whole_step_tflops"] = round(tot_fl / (dt / args.steps) / 1e12, 1)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(R, Hd)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

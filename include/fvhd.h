@@ -88,7 +88,7 @@ int fvhd_hidden_size(const fvhd_ctx* ctx);  /* 3072     */
  * on the caller's stream.  fvhd_profile_read synchronises those events and returns, per kernel
  * class, the accumulated milliseconds and launch count since the last reset.  Class names:
  * "stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv", "gemm_proj",
- * "layernorm", "attention", "head", "projector". */
+ * "layernorm", "attention", "head", "projector", "ffn_fused". */
 int fvhd_profile_enable(fvhd_ctx* ctx, int on);
 int fvhd_profile_reset(fvhd_ctx* ctx);
 int fvhd_profile_read(fvhd_ctx* ctx, int max_classes, const char** names, double* ms, int64_t* launches,
@@ -109,9 +109,17 @@ int fvhd_op_attention(fvhd_stream_t stream, const void* qkv, void* out, int B, i
 /* stem[0] (mci.py:563-574): img [B,3,R,R] of dtype -> out [B,R/2,R/2,96] bf16; w fp32 [27][96] (k = ci*9+ky*3+kx). */
 int fvhd_op_stem_conv(fvhd_stream_t stream, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R);
 /* SEBlock + GELU of conv_exp (mci.py:72-81,198): y [B,T,C] bf16 -> out [B,T,C] of out_dtype;
- * pooled, scale: fp32 scratch [B,C]; wr fp32 [RD][C]; we fp32 [C][RD]. */
+ * pooled: fp32 scratch [B*(C+RD)]; scale: fp32 scratch [B,C]; wr fp32 [RD][C]; we fp32 [C][RD]; RD % 4 == 0. */
 int fvhd_op_se_head(fvhd_stream_t stream, const void* y, float* pooled, float* scale, const float* wr, const float* br,
                     const float* we, const float* be, void* out, int out_dtype, int B, int T, int C, int RD);
+
+/* Fused ConvFFN MLP (mci.py:922-926 + 1106-1109): X <- X + ls * (gelu(A.W1^T + b1).W2^T + b2), in place on X [M,C] bf16.
+ * C in {96,192,384}.  A [M,C] bf16; W1 bf16 [4C][C]; b1 fp32 [4C]; b2, ls fp32 [C];
+ * W2s = fc2 weight [C][4C] repacked slice-major [4C/HS][C][HS], HS = fvhd_ffn_slice(C), with the hidden axis permuted
+ * inside every 32-chunk: position 16kb+8half+j holds hidden unit 16kb+8(j>>2)+4half+(j&3)  (kb,half in {0,1}, j in 0..7). */
+int fvhd_op_ffn_fused(fvhd_stream_t stream, const void* A, const void* W1, const float* b1, const void* W2s,
+                      const float* b2, const float* ls, void* X, int M, int C);
+int fvhd_ffn_slice(int C);
 
 #ifdef __cplusplus
 }

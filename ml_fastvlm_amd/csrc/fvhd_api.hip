@@ -4,6 +4,7 @@
 // structure follows fastvithd() (mci.py:1454-1478).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -22,6 +23,8 @@ int fvhd_launch_stem_conv(hipStream_t, const void*, int, void*, const float*, co
 int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, const float*, const float*, const float*,
                         void*, int, int, int, int, int);
 int fvhd_launch_cast_to_bf16(hipStream_t, const void*, int, void*, long);
+int fvhd_launch_ffn_fused(hipStream_t, const void*, const void*, const float*, const void*, const float*, const float*, void*, int, int);
+int fvhd_ffn_slice(int);
 }
 
 namespace {
@@ -86,7 +89,7 @@ struct Packer {          // builds the packed weight image on the host; offsets 
 
 struct DwW { size_t w = 0, b = 0; int K = 0; };                    // taps fp32 [K*K][Cout], bias fp32 [Cout]
 struct GemmW { size_t w = 0, b = 0; int N = 0, K = 0; bool has_bias = false; };
-struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; };
+struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; size_t w2s = 0; bool fused = false; };   // w2s: fc2 weight in the fused kernel's layout
 struct RepBlockW { DwW mixer; FfnW ffn; };
 struct AttnBlockW { size_t ln_w = 0, ln_b = 0, ls1 = 0; GemmW qkv, proj; FfnW ffn; };
 struct DownW { DwW dw; GemmW pw; };
@@ -106,8 +109,8 @@ struct Model {
 struct ProfRec { int cls; hipEvent_t a, b; };
 
 const char* kClassNames[] = {"stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv",
-                             "gemm_proj", "layernorm", "attention", "head", "projector"};
-enum { C_STEM, C_DW3, C_DW7, C_DWDOWN, C_FC1, C_FC2, C_1X1, C_QKV, C_PROJ, C_LN, C_ATT, C_HEAD, C_PROJECTOR, C_COUNT };
+                             "gemm_proj", "layernorm", "attention", "head", "projector", "ffn_fused"};
+enum { C_STEM, C_DW3, C_DW7, C_DWDOWN, C_FC1, C_FC2, C_1X1, C_QKV, C_PROJ, C_LN, C_ATT, C_HEAD, C_PROJECTOR, C_FFN, C_COUNT };
 
 }  // namespace
 
@@ -125,6 +128,7 @@ struct fvhd_ctx {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     int ws_batch = 0, ws_hidden = 0;
+    bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -213,6 +217,24 @@ bool pack_ffn(fvhd_ctx* c, Packer& pk, const std::string& p, const std::string& 
     if (!pack_dw(c, pk, p + ".convffn.conv.conv.weight", "", C, 7, &out->dw7, &s, &b)) return false;
     if (!pack_gemm(c, pk, p + ".convffn.fc1.weight", p + ".convffn.fc1.bias", 4 * C, C, true, &out->fc1)) return false;
     if (!pack_gemm(c, pk, p + ".convffn.fc2.weight", p + ".convffn.fc2.bias", C, 4 * C, true, &out->fc2)) return false;
+    // fc2 weight for the fused MLP kernel (ffn_fused.hip): slice-major [4C/HS][C][HS], hidden axis permuted inside
+    // every 32-chunk so that position 16kb + 8half + j holds hidden unit 16kb + 8(j>>2) + 4half + (j&3).
+    const int HS = fvhd_ffn_slice(C);
+    if (HS > 0) {
+        const HostTensor* w2 = find(c, p + ".convffn.fc2.weight", {C, 4 * C, 1, 1});
+        if (!w2) return false;
+        const int HID = 4 * C, NSL = HID / HS;
+        std::vector<float> t((size_t)C * HID);
+        for (int sl = 0; sl < NSL; ++sl)
+            for (int n = 0; n < C; ++n)
+                for (int pos = 0; pos < HS; ++pos) {
+                    const int ch = pos >> 5, q = pos & 31, kb = q >> 4, hf = (q >> 3) & 1, j = q & 7;
+                    const int h = 16 * kb + 8 * (j >> 2) + 4 * hf + (j & 3);
+                    t[((size_t)sl * C + n) * HS + pos] = w2->data[(size_t)n * HID + sl * HS + ch * 32 + h];
+                }
+        out->w2s = pk.add_bf16(t.data(), t.size());
+        out->fused = true;
+    }
     return pack_vec(c, pk, ls_key, {C, 1, 1}, &out->ls);
 }
 
@@ -238,7 +260,7 @@ Ws carve(const fvhd_ctx* c, char* base, int B, int hidden)
     w.tok = take(Tn * B * kOutDim * 2);
     w.ph = take(Tn * B * (size_t)(hidden > 0 ? hidden : 1) * 2);
     w.cast = take(Tn * B * kOutDim * 2);
-    w.pooled = (float*)take((size_t)B * kOutDim * 4);
+    w.pooled = (float*)take((size_t)B * (kOutDim + kSeRd) * 4);
     w.scale = (float*)take((size_t)B * kOutDim * 4);
     w.total = off;
     return w;
@@ -313,6 +335,13 @@ int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, in
     const int M = B * H * Wd;
     int e;
     if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0))) return e;
+    if (f.fused && c->use_fused_ffn) {
+        Scope s(c, st, C_FFN);
+        CHECK_LAUNCH(fvhd_launch_ffn_fused(st, w.A, c->wdev + f.fc1.w, c->wp<float>(f.fc1.b), c->wdev + f.w2s,
+                                           c->wp<float>(f.fc2.b), c->wp<float>(f.ls), x, M, C),
+                     "fused ffn launch");
+        return 0;
+    }
     if ((e = run_gemm(c, st, C_FC1, c->wdev, f.fc1, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_BIAS_GELU))) return e;
     return run_gemm(c, st, C_FC2, c->wdev, f.fc2, w.H, c->wp<float>(f.ls), x, x, M, FVHD_EPI_BIAS_LS_RESID);
 }
@@ -433,6 +462,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->device = device;
     c->R = image_size;
     c->max_batch = max_batch;
+    if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
     *out = c;
     return 0;
 }
@@ -672,6 +702,13 @@ int fvhd_op_se_head(fvhd_stream_t st, const void* y, float* pooled, float* scale
 {
     int e = fvhd_launch_se_head((hipStream_t)st, y, pooled, scale, wr, br, we, be, out, out_dtype, B, T, C, RD);
     return e ? hip_fail("fvhd_op_se_head", (hipError_t)e) : 0;
+}
+
+int fvhd_op_ffn_fused(fvhd_stream_t st, const void* A, const void* W1, const float* b1, const void* W2s, const float* b2,
+                      const float* ls, void* X, int M, int C)
+{
+    int e = fvhd_launch_ffn_fused((hipStream_t)st, A, W1, b1, W2s, b2, ls, X, M, C);
+    return e ? hip_fail("fvhd_op_ffn_fused", (hipError_t)e) : 0;
 }
 
 }  // extern "C"

@@ -92,32 +92,46 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const bf16* __restrict__ y
 }
 
 // ---- SE MLP: scale[b] = sigmoid(We . relu(Wr . pooled[b] + br) + be) -----------------------------
-// Wr fp32 [RD][C], We fp32 [C][RD].  One workgroup per image; RD <= 256.
-__global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
-                                                     const float* __restrict__ br, const float* __restrict__ we,
-                                                     const float* __restrict__ be, float* __restrict__ scale,
-                                                     int C, int RD)
+// Wr fp32 [RD][C], We fp32 [C][RD].  Two small launches so that B*RD/4 resp. B*C/256 workgroups
+// (1536 / 384 at B = 32) share the 2 x 2.4 MB of weights through L2 instead of 32 workgroups
+// streaming them serially.
+// hidden[b][r] = relu(Wr[r] . pooled[b] + br[r]);  grid (RD/4, B), one wave per hidden unit.
+__global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict__ pooled, const float* __restrict__ wr,
+                                                        const float* __restrict__ br, float* __restrict__ hidden,
+                                                        int C, int RD)
 {
-    extern __shared__ float sm[];       // pooled row [C] then hidden [RD]
-    float* sp = sm;
-    float* sh = sm + C;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < C; i += 256) sp[i] = pooled[(size_t)b * C + i];
-    __syncthreads();
-    for (int r = wave; r < RD; r += 4) {            // one wave per hidden unit: coalesced dot over C
-        const float* wrow = wr + (size_t)r * C;
-        float s = 0.f;
-        for (int i = lane; i < C; i += 64) s = __builtin_fmaf(wrow[i], sp[i], s);
-        s = wave_sum(s);
-        if (lane == 0) sh[r] = fmaxf(s + br[r], 0.0f);
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= RD) return;
+    const float* wrow = wr + (size_t)r * C;
+    const float* p = pooled + (size_t)b * C;
+    float s = 0.f;
+    for (int i = lane * 4; i < C; i += 256) {
+        const f32x4 a = *(const f32x4*)(wrow + i), v = *(const f32x4*)(p + i);
+        s += a[0] * v[0] + a[1] * v[1] + a[2] * v[2] + a[3] * v[3];
     }
+    s = wave_sum(s);
+    if (lane == 0) hidden[(size_t)b * RD + r] = fmaxf(s + br[r], 0.0f);
+}
+
+// scale[b][c] = sigmoid(We[c] . hidden[b] + be[c]);  grid (C/256, B), one thread per channel.
+__global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict__ hidden, const float* __restrict__ we,
+                                                        const float* __restrict__ be, float* __restrict__ scale,
+                                                        int C, int RD)
+{
+    extern __shared__ float sh[];       // hidden row [RD]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < RD; i += 256) sh[i] = hidden[(size_t)b * RD + i];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float* wrow = we + (size_t)c * RD;
-        float s = be[c];
-        for (int r = 0; r < RD; ++r) s = __builtin_fmaf(wrow[r], sh[r], s);
-        scale[(size_t)b * C + c] = sigmoidf_fast(s);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* wrow = we + (size_t)c * RD;
+    float s = be[c];
+    for (int r = 0; r < RD; r += 4) {
+        const f32x4 a = *(const f32x4*)(wrow + r);
+        s += a[0] * sh[r] + a[1] * sh[r + 1] + a[2] * sh[r + 2] + a[3] * sh[r + 3];
     }
+    scale[(size_t)b * C + c] = sigmoidf_fast(s);
 }
 
 // ---- out[b,t,c] = gelu(y[b,t,c] * scale[b,c]) in the caller's dtype -------------------------------
@@ -140,10 +154,13 @@ extern "C" int fvhd_launch_se_head(hipStream_t st, const void* y, float* pooled,
                                    const float* br, const float* we, const float* be, void* out, int out_dtype,
                                    int B, int T, int C, int RD)
 {
-    if (C % 8 || RD > 1024) return (int)hipErrorInvalidValue;
+    if (C % 8 || RD % 4 || RD > 1024) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(se_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, (const bf16*)y, pooled, T, C);
-    hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(256), (size_t)(C + RD) * sizeof(float), st,
-                       pooled, wr, br, we, be, scale, C, RD);
+    // `pooled` is [B, C + RD]: the pooled row followed by the SE hidden row
+    float* hidden = pooled + (size_t)B * C;
+    hipLaunchKernelGGL(se_reduce_kernel, dim3((RD + 3) / 4, B), dim3(256), 0, st, pooled, wr, br, hidden, C, RD);
+    hipLaunchKernelGGL(se_expand_kernel, dim3((C + 255) / 256, B), dim3(256), (size_t)RD * sizeof(float), st,
+                       hidden, we, be, scale, C, RD);
     const long total8 = (long)B * T * C / 8;
     dim3 grid((unsigned)((total8 + 255) / 256));
     if (out_dtype == FVHD_F32) hipLaunchKernelGGL(se_scale_gelu_kernel<float>, grid, dim3(256), 0, st, (const bf16*)y, scale, (float*)out, T, C, total8);

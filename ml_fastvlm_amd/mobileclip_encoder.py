@@ -121,7 +121,10 @@ class MobileCLIPVisionTower(nn.Module):
                                                   size={"shortest_edge": r})
         self.vision_tower = FastViTHDWeights()
         self.vision_tower.requires_grad_(bool(self.tune_vision_tower))
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_dirty())
+        # load_state_dict may be called on the tower, on an ancestor (the whole LLaVA model) or on any
+        # descendant (tests load into `.vision_tower.model`): hook every module of the subtree.
+        for mod in self.modules():
+            mod.register_load_state_dict_post_hook(lambda module, incompatible: self._mark_dirty())
         self.is_loaded = True
         self._dirty = True
 

@@ -60,6 +60,21 @@ def _run_with_taps(tower, images):
     return out, taps
 
 
+def _reference_bf16_error(tower, images, out_fp32, tag):
+    """The reference's OWN bf16 execution (tower.to(bfloat16), bf16 images; PyTorch CPU kernels) measured
+    against its fp32 execution on the same inputs/weights: the evidence the stated GPU tolerance rests on."""
+    tower.to(torch.bfloat16)
+    ob = tower(images.to(torch.bfloat16)).float()
+    tower.to(torch.float32)
+    d = (ob.double() - out_fp32.double()).flatten()
+    w = out_fp32.double().flatten()
+    rel = (d.norm() / w.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(ob.double().flatten(), w, dim=0).item()
+    mx = (d.abs().max() / w.abs().max()).item()
+    print(f"reference bf16 vs its own fp32 @{tag}: rel-L2 {rel:.3e} cos {cos:.6f} max-abs/absmax {mx:.3e}")
+    return {"ref_bf16_rel_l2": np.float64(rel), "ref_bf16_cos": np.float64(cos), "ref_bf16_maxabs": np.float64(mx)}
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -91,6 +106,7 @@ def main():
         arrays[f"tap{i:02d}_shape"] = np.array(t.shape, dtype=np.int64)
         arrays[f"tap{i:02d}"] = t.flatten()[::TAP_STRIDE].numpy().copy()
         print(f"tap{i:02d}", tuple(t.shape), "absmax %.3f rms %.3f" % (t.abs().max(), t.pow(2).mean().sqrt()))
+    arrays.update(_reference_bf16_error(tower, images, out, "256"))
     np.savez_compressed(os.path.join(GOLD, "tower_r256_b2.npz"), **arrays)
 
     # ---- 1024x1024, B=1, token subsample ------------------------------------------------------
@@ -101,8 +117,9 @@ def main():
     out = tower(images)
     print("reference 1024^2 fp32 B=1: %.2f s" % (time.time() - t0))
     assert out.shape == (1, 256, 3072)
+    bf = _reference_bf16_error(tower, images, out, "1024")
     np.savez_compressed(
-        os.path.join(GOLD, "tower_r1024_b1.npz"),
+        os.path.join(GOLD, "tower_r1024_b1.npz"), **bf,
         out_tok8=out[:, ::8].numpy().copy(), weight_seed=np.int64(WEIGHT_SEED), image_seed=np.int64(1),
         mean=np.float64(out.double().mean()), absmean=np.float64(out.double().abs().mean()),
         l2=np.float64(out.double().pow(2).sum().sqrt()), absmax=np.float64(out.abs().max()),

@@ -1,0 +1,297 @@
+"""Per-op parity of the HIP kernels (called through the C ABI) against the oracle's functional
+restatement / torch fp32 on CPU, on the same seeded inputs.
+
+Tolerances (stated here, once): inputs are rounded to bf16 first so both sides see identical
+operands; the kernels accumulate in fp32 and round once on store, so the budget is one bf16
+rounding of the result (2^-9 relative) plus fp32 accumulation-order noise:
+    |got - want| <= 1.0e-2 * |want| + 1.0e-2 * rms(want)
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ml_fastvlm_amd import _lib
+from oracle import fastvithd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _close(got, want, rtol=1e-2, atol_rms=1e-2, what=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    rms = want.pow(2).mean().sqrt().item()
+    err = (got - want).abs()
+    bound = rtol * want.abs() + atol_rms * rms
+    bad = (err > bound).sum().item()
+    assert bad == 0, f"{what}: {bad}/{err.numel()} elements out of tolerance, max err {err.max():.4g}, rms {rms:.4g}"
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _gemm(A, W, bias, ls, resid, epi, out_dtype=torch.bfloat16, inplace=False):
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    a, w = _bf(A).to(DEV), _bf(W).to(DEV)
+    b = bias.float().to(DEV) if bias is not None else None
+    l = ls.float().to(DEV) if ls is not None else None
+    r = _bf(resid).to(DEV) if resid is not None else None
+    out = r if inplace else torch.empty(M, N, dtype=out_dtype, device=DEV)
+    _lib.check(lib.fvhd_op_gemm(_stream(), _p(a), _p(w), _p(b), _p(l), _p(r), _p(out), M, N, K, epi,
+                                _lib.dtype_code(out.dtype)), "fvhd_op_gemm")
+    torch.cuda.synchronize()
+    return out
+
+
+def test_gemm_identity_asymmetric():
+    # A = I, asymmetric W: out must equal W^T exactly (catches swapped C/D row/col mappings)
+    n = 128
+    W = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125.0     # exactly representable in bf16? |v|<=125 yes
+    out = _gemm(torch.eye(n), W, None, None, None, _lib.EPI_NONE)
+    assert torch.equal(out.float().cpu(), W.t())
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (300, 96, 96, _lib.EPI_BIAS_GELU),          # NF=3 BK=32, ragged M   (stem 1x1, stage-0 fc2 shape class)
+    (256, 384, 96, _lib.EPI_BIAS_GELU),         # NF=4 BK=32             (stage-0 fc1)
+    (513, 192, 384, _lib.EPI_BIAS_LS_RESID),    # NF=3 BK=64, ragged M   (fc2 + layer scale + residual)
+    (1000, 2304, 768, _lib.EPI_NONE),           # qkv, no bias
+    (77, 768, 3072, _lib.EPI_BIAS_LS_RESID),    # stage-3 fc2, long K
+    (64, 896, 3072, _lib.EPI_BIAS),             # projector
+    (1, 96, 96, _lib.EPI_BIAS),                 # single row
+])
+def test_gemm_epilogues(M, N, K, epi):
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    bias = _rand(N, seed=3, scale=0.1) if epi != _lib.EPI_NONE else None
+    ls = torch.rand(N, generator=torch.Generator().manual_seed(4)) if epi == _lib.EPI_BIAS_LS_RESID else None
+    resid = _rand(M, N, seed=5) if epi == _lib.EPI_BIAS_LS_RESID else None
+    got = _gemm(A, W, bias, ls, resid, epi)
+    y = _bf(A).float() @ _bf(W).float().t()
+    if bias is not None:
+        y = y + bias
+    if epi == _lib.EPI_BIAS_GELU:
+        y = O.gelu(y)
+    if epi == _lib.EPI_BIAS_LS_RESID:
+        y = _bf(resid).float() + ls * y
+    _close(got, y, what=f"gemm {M}x{N}x{K} epi{epi}")
+
+
+def test_gemm_inplace_residual_and_f32_out():
+    M, N, K = 200, 384, 1536
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    bias, ls, resid = _rand(N, seed=3, scale=0.1), torch.full((N,), 0.5), _rand(M, N, seed=5)
+    got = _gemm(A, W, bias, ls, resid, _lib.EPI_BIAS_LS_RESID, inplace=True)
+    want = _bf(resid).float() + ls * (_bf(A).float() @ _bf(W).float().t() + bias)
+    _close(got, want, what="gemm in-place residual")
+    got32 = _gemm(A, W, bias, None, None, _lib.EPI_BIAS, out_dtype=torch.float32)
+    assert got32.dtype == torch.float32
+    _close(got32, _bf(A).float() @ _bf(W).float().t() + bias, rtol=1e-4, atol_rms=1e-4, what="gemm f32 out")
+    got16 = _gemm(A, W, bias, None, None, _lib.EPI_BIAS, out_dtype=torch.float16)
+    _close(got16, _bf(A).float() @ _bf(W).float().t() + bias, rtol=2e-3, atol_rms=2e-3, what="gemm f16 out")
+
+
+def test_gemm_rejects_bad_shapes():
+    lib = _lib.load()
+    a = torch.zeros(8, 40, dtype=torch.bfloat16, device=DEV)
+    assert lib.fvhd_op_gemm(_stream(), _p(a), _p(a), None, None, None, _p(a), 8, 8, 40, 0, 2) != 0   # K % 32, N % 16
+
+
+# ------------------------------------------------------------------------------------------- fused FFN
+def _pack_w2(W2, HS):
+    """fc2 weight [C, 4C] -> slice-major [4C/HS, C, HS] with the documented in-chunk hidden permutation."""
+    Cc, HID = W2.shape
+    pos = torch.arange(HS)
+    ch, q = pos >> 5, pos & 31
+    kb, hf, j = q >> 4, (q >> 3) & 1, q & 7
+    src = ch * 32 + 16 * kb + 8 * (j >> 2) + 4 * hf + (j & 3)
+    return W2.reshape(Cc, HID // HS, HS)[:, :, src].permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("C,M", [(96, 300), (192, 256), (384, 131), (384, 1024), (96, 1)])
+def test_ffn_fused(C, M):
+    lib = _lib.load()
+    HID = 4 * C
+    HS = lib.fvhd_ffn_slice(C)
+    assert HS in (32, 64)
+    A, X = _bf(_rand(M, C, seed=1)), _bf(_rand(M, C, seed=2))
+    W1, W2 = _bf(_rand(HID, C, seed=3, scale=C ** -0.5)), _bf(_rand(C, HID, seed=4, scale=HID ** -0.5))
+    b1, b2, ls = _rand(HID, seed=5, scale=0.2), _rand(C, seed=6, scale=0.2), torch.rand(C, generator=torch.Generator().manual_seed(7))
+    ad, xd, w1d, w2d = A.to(DEV), X.to(DEV), W1.to(DEV), _pack_w2(W2, HS).to(DEV)
+    b1d, b2d, lsd = b1.to(DEV), b2.to(DEV), ls.to(DEV)
+    _lib.check(lib.fvhd_op_ffn_fused(_stream(), _p(ad), _p(w1d), _p(b1d), _p(w2d), _p(b2d), _p(lsd), _p(xd), M, C), "ffn_fused")
+    torch.cuda.synchronize()
+    hid = _bf(O.gelu(A.float() @ W1.float().t() + b1)).float()          # the kernel rounds the hidden tile to bf16
+    want = X.float() + ls * (hid @ W2.float().t() + b2)
+    _close(xd, want, what=f"ffn_fused C{C} M{M}")
+
+
+def test_ffn_fused_matches_two_gemm_route():
+    """Same math as fc1(+GELU) -> fc2(+ls,+resid) through the plain GEMM kernel."""
+    lib = _lib.load()
+    C, M = 192, 640
+    HID, HS = 4 * C, lib.fvhd_ffn_slice(192)
+    A, X = _rand(M, C, seed=1), _rand(M, C, seed=2)
+    W1, W2 = _rand(HID, C, seed=3, scale=C ** -0.5), _rand(C, HID, seed=4, scale=HID ** -0.5)
+    b1, b2, ls = _rand(HID, seed=5, scale=0.2), _rand(C, seed=6, scale=0.2), torch.full((C,), 0.3)
+    hid = _gemm(A, W1, b1, None, None, _lib.EPI_BIAS_GELU)
+    two = _gemm(hid.float().cpu(), W2, b2, ls, X, _lib.EPI_BIAS_LS_RESID)
+    ad, xd, w1d, w2d = _bf(A).to(DEV), _bf(X).to(DEV), _bf(W1).to(DEV), _pack_w2(_bf(W2), HS).to(DEV)
+    b1d, b2d, lsd = b1.to(DEV), b2.to(DEV), ls.to(DEV)
+    _lib.check(lib.fvhd_op_ffn_fused(_stream(), _p(ad), _p(w1d), _p(b1d), _p(w2d), _p(b2d), _p(lsd), _p(xd), M, C), "ffn_fused")
+    torch.cuda.synchronize()
+    _close(xd, two, rtol=8e-3, atol_rms=8e-3, what="fused vs two-GEMM route")
+
+
+# ------------------------------------------------------------------------------------------- depthwise
+def _pack_dw(w):   # [Cout,1,K,K] -> fp32 [K*K][Cout]
+    co, _, k, _ = w.shape
+    return w.reshape(co, k * k).t().contiguous()
+
+
+@pytest.mark.parametrize("K,S,mult,gelu,Cin,H,W", [
+    (3, 1, 1, 0, 96, 13, 17),      # RepMixer, CS=96, ragged strips
+    (3, 1, 1, 0, 192, 9, 9),       # CS=64
+    (3, 2, 1, 1, 96, 14, 18),      # stem[1]
+    (7, 1, 1, 0, 384, 11, 7),      # ConvFFN dw7 / RepCPE, W < halo+strip
+    (7, 1, 1, 0, 96, 4, 4),        # map smaller than the kernel (stage 4 at 256^2)
+    (7, 2, 2, 1, 96, 16, 12),      # PatchEmbed 96 -> 192
+    (7, 2, 2, 1, 768, 6, 6),       # PatchEmbed 768 -> 1536
+    (3, 1, 2, 0, 1536, 4, 4),      # conv_exp
+])
+def test_dwconv(K, S, mult, gelu, Cin, H, W):
+    lib = _lib.load()
+    B, Cout = 2, Cin * mult
+    x = _bf(_rand(B, Cin, H, W, seed=1))
+    w = _rand(Cout, 1, K, K, seed=2, scale=1.0 / K)
+    b = _rand(Cout, seed=3, scale=0.2)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    OH, OW = (H + 2 * (K // 2) - K) // S + 1, (W + 2 * (K // 2) - K) // S + 1
+    y = torch.empty(B, OH, OW, Cout, dtype=torch.bfloat16, device=DEV)
+    wd, bd = _pack_dw(w).to(DEV), b.to(DEV)
+    _lib.check(lib.fvhd_op_dwconv(_stream(), _p(xn), _p(y), _p(wd), _p(bd), B, H, W, Cin, K, S, mult, gelu), "dwconv")
+    torch.cuda.synchronize()
+    want = F.conv2d(x.float(), w, b, stride=S, padding=K // 2, groups=Cin)
+    if gelu:
+        want = O.gelu(want)
+    _close(y.permute(0, 3, 1, 2), want, what=f"dwconv K{K} S{S} m{mult}")
+
+
+def test_dwconv_no_bias():
+    lib = _lib.load()
+    B, C, H, W = 1, 64, 8, 8
+    x, w = _bf(_rand(B, C, H, W, seed=1)), _rand(C, 1, 7, 7, seed=2, scale=1 / 7)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=DEV)
+    wd = _pack_dw(w).to(DEV)
+    _lib.check(lib.fvhd_op_dwconv(_stream(), _p(xn), _p(y), _p(wd), None, B, H, W, C, 7, 1, 1, 0), "dwconv")
+    torch.cuda.synchronize()
+    _close(y.permute(0, 3, 1, 2), F.conv2d(x.float(), w, None, padding=3, groups=C), what="dwconv no bias")
+
+
+# ------------------------------------------------------------------------------------------- layernorm
+@pytest.mark.parametrize("M,C", [(37, 768), (5, 1536), (9, 96), (3, 2048)])
+def test_layernorm(M, C):
+    lib = _lib.load()
+    x = _bf(_rand(M, C, seed=1) * 2 + 0.5)
+    w, b = torch.rand(C) + 0.5, _rand(C, seed=2, scale=0.1)
+    y = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)      # keep device copies alive across the async launch
+    _lib.check(lib.fvhd_op_layernorm(_stream(), _p(xd), _p(y), _p(wd), _p(bd), M, C, 1e-5), "layernorm")
+    torch.cuda.synchronize()
+    want = O.layernorm_channel(x.float().t().reshape(1, C, M, 1), w, b)[0, :, :, 0].t()
+    _close(y, want, what=f"layernorm {M}x{C}")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attention_ref(qkv, B, N, C):
+    nh = C // 32
+    t = qkv.float().reshape(B, N, 3, nh, 32).permute(2, 0, 3, 1, 4)
+    q, k, v = t.unbind(0)
+    a = ((q * 32 ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(B * N, C)
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 16, 64), (1, 64, 768), (2, 100, 96), (1, 256, 1536), (2, 1024, 96), (1, 576, 64)])
+def test_attention(B, N, C):
+    lib = _lib.load()
+    qkv = _bf(_rand(B * N, 3 * C, seed=1, scale=1.5))
+    out = torch.empty(B * N, C, dtype=torch.bfloat16, device=DEV)
+    qd = qkv.to(DEV)
+    _lib.check(lib.fvhd_op_attention(_stream(), _p(qd), _p(out), B, N, C), "attention")
+    torch.cuda.synchronize()
+    _close(out, _attention_ref(qkv, B, N, C), rtol=2e-2, atol_rms=2e-2, what=f"attention B{B} N{N} C{C}")
+
+
+def test_attention_forced_rescale():
+    """One key far above the rest late in the sequence: the running max jumps at a later tile, so the
+    online-softmax rescale branch is exercised on every query (guide rule 26)."""
+    lib = _lib.load()
+    B, N, C = 1, 512, 64
+    qkv = _rand(B * N, 3 * C, seed=3)
+    q = qkv[:, :C]
+    spike = 400                                                   # key index in tile 6 of 8
+    qkv[spike, C:2 * C] = 6.0 * q.mean(0) / q.mean(0).norm() * 32 ** 0.5 + qkv[spike, C:2 * C]
+    qkv[:, :C] += 1.5 * q.mean(0, keepdim=True).sign()           # make most q.k_spike large and positive
+    qkv = _bf(qkv)
+    out = torch.empty(B * N, C, dtype=torch.bfloat16, device=DEV)
+    qd = qkv.to(DEV)
+    _lib.check(lib.fvhd_op_attention(_stream(), _p(qd), _p(out), B, N, C), "attention")
+    torch.cuda.synchronize()
+    _close(out, _attention_ref(qkv, B, N, C), rtol=2e-2, atol_rms=2e-2, what="attention spike")
+
+
+# ------------------------------------------------------------------------------------------- stem / head
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_stem_conv(dtype):
+    lib = _lib.load()
+    B, R = 2, 64
+    img = torch.rand(B, 3, R, R, generator=torch.Generator().manual_seed(0)).to(dtype)
+    w, b = _rand(96, 3, 3, 3, seed=1, scale=0.5), _rand(96, seed=2, scale=0.1)
+    wd = w.reshape(96, 27).t().contiguous().to(DEV)
+    out = torch.empty(B, R // 2, R // 2, 96, dtype=torch.bfloat16, device=DEV)
+    imd, bd = img.to(DEV), b.to(DEV)
+    _lib.check(lib.fvhd_op_stem_conv(_stream(), _p(imd), _lib.dtype_code(dtype), _p(out), _p(wd), _p(bd), B, R), "stem")
+    torch.cuda.synchronize()
+    want = O.gelu(F.conv2d(img.float(), w, b, stride=2, padding=1))
+    _close(out.permute(0, 3, 1, 2), want, what=f"stem conv {dtype}")
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_se_head(out_dtype):
+    lib = _lib.load()
+    B, T, Cc, RD = 3, 16, 3072, 192
+    y = _bf(_rand(B, T, Cc, seed=1))
+    wr, br = _rand(RD, Cc, seed=2, scale=Cc ** -0.5), _rand(RD, seed=3, scale=0.1)
+    we, be = _rand(Cc, RD, seed=4, scale=RD ** -0.5), _rand(Cc, seed=5, scale=0.1)
+    pooled = torch.empty(B * (Cc + RD), device=DEV)
+    scale = torch.empty(B, Cc, device=DEV)
+    out = torch.empty(B, T, Cc, dtype=out_dtype, device=DEV)
+    yd, wrd, brd, wed, bed = (t.to(DEV) for t in (y, wr, br, we, be))
+    _lib.check(lib.fvhd_op_se_head(_stream(), _p(yd), _p(pooled), _p(scale), _p(wrd), _p(brd),
+                                   _p(wed), _p(bed), _p(out), _lib.dtype_code(out_dtype), B, T, Cc, RD), "se_head")
+    torch.cuda.synchronize()
+    yf = y.float()
+    s = torch.sigmoid(F.linear(F.relu(F.linear(yf.mean(1), wr, br)), we, be))
+    want = O.gelu(yf * s[:, None, :])
+    _close(out, want, what=f"se head {out_dtype}")
