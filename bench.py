@@ -171,11 +171,12 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     images = torch.rand((B, 3, R, R), generator=g).to(dev, torch.bfloat16)      # synthetic, in [0,1), HBM-resident
 
+    @torch.no_grad()                             # inference (predict.py:55 runs generate() under torch.inference_mode())
+    def local_step():
+        return tower(images) if args.tower_only else fv.encode_images(tower, proj, images)
+
     def step():
-        if args.tower_only:
-            local = tower(images)
-        else:
-            local = fv.encode_images(tower, proj, images)
+        local = local_step()
         if world > 1:
             return D.all_gather_tokens(local, B * world)
         return local
@@ -220,7 +221,7 @@ def main():
         ctx.profile_reset()
         psteps = max(2, min(5, args.steps))
         for _ in range(psteps):
-            fv.encode_images(tower, proj, images) if not args.tower_only else tower(images)
+            local_step()                             # rank-local: no collective in the profiled pass
         torch.cuda.synchronize()
         prof = ctx.profile_read()
         ctx.profile_enable(False)

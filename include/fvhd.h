@@ -83,6 +83,22 @@ int fvhd_encode_images(fvhd_ctx* ctx, const void* images, int img_dtype, int bat
 int fvhd_num_tokens(const fvhd_ctx* ctx);   /* (R/64)^2 */
 int fvhd_hidden_size(const fvhd_ctx* ctx);  /* 3072     */
 
+/* ---- step-level execution (parity tests / debugging) ---------------------------------------------
+ * The tower is a list of "steps", one per forward() of a reference module on the running activation, in
+ * the execution order of FastViT.forward (mci.py:1427-1451): step 0 = convolutional_stem, then per stage
+ * [RepCPE], every RepMixerBlock / AttentionBlock, [PatchEmbed], and last conv_exp (+SE+GELU).
+ * fvhd_step_info: kind 0 stem, 1 RepCPE, 2 RepMixerBlock, 3 AttentionBlock, 4 PatchEmbed, 5 conv_exp;
+ * (c_in,h_in) / (c_out,h_out) = channels and side of the NHWC activation entering / leaving the step.
+ * fvhd_run_steps runs steps first..last (inclusive) on x_in and writes the result to x_out, both NHWC
+ * bf16 device buffers ([batch,h,h,c]; for first == 0 x_in is the NCHW bf16 image batch, for the last
+ * step x_out is the [batch,T,3072] bf16 token tensor).  This is how the tests feed every block the
+ * oracle's input for that block ("teacher forcing") instead of comparing only after 44 blocks. */
+int fvhd_num_steps(const fvhd_ctx* ctx);
+int fvhd_step_info(const fvhd_ctx* ctx, int step, int* kind, int* stage, int* block, int* c_in, int* h_in,
+                   int* c_out, int* h_out);
+int fvhd_run_steps(fvhd_ctx* ctx, int first, int last, const void* x_in, int batch, void* x_out,
+                   fvhd_stream_t stream);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * With profiling on, every kernel launch inside fvhd_encode/fvhd_project is bracketed by HIP events
  * on the caller's stream.  fvhd_profile_read synchronises those events and returns, per kernel

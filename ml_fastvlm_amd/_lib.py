@@ -34,6 +34,9 @@ def _declare(lib) -> None:
         "fvhd_encode": (ci, [vp, vp, ci, ci, vp, ci, vp]),
         "fvhd_project": (ci, [vp, vp, ci, ci, vp, ci, vp]),
         "fvhd_encode_images": (ci, [vp, vp, ci, ci, vp, ci, vp]),
+        "fvhd_num_steps": (ci, [vp]),
+        "fvhd_step_info": (ci, [vp, ci] + [C.POINTER(ci)] * 7),
+        "fvhd_run_steps": (ci, [vp, ci, ci, vp, ci, vp, vp]),
         "fvhd_num_tokens": (ci, [vp]),
         "fvhd_hidden_size": (ci, [vp]),
         "fvhd_profile_enable": (ci, [vp, ci]),
@@ -147,6 +150,22 @@ class Context:
     def encode_images(self, images, out) -> None:
         check(load().fvhd_encode_images(self._h, ptr(images), dtype_code(images.dtype), images.shape[0], ptr(out),
                                         dtype_code(out.dtype), stream_ptr(images.device)), "fvhd_encode_images")
+
+    # ---- step-level execution (tests) ----
+    STEP_KINDS = ("stem", "cpe", "repmixer_block", "attention_block", "patch_embed", "conv_exp")
+
+    def steps(self):
+        """[(kind, stage, block, c_in, h_in, c_out, h_out)] in execution order."""
+        lib, out = load(), []
+        for i in range(lib.fvhd_num_steps(self._h)):
+            v = [C.c_int(0) for _ in range(7)]
+            check(lib.fvhd_step_info(self._h, i, *[C.byref(x) for x in v]), "fvhd_step_info")
+            out.append((self.STEP_KINDS[v[0].value],) + tuple(x.value for x in v[1:]))
+        return out
+
+    def run_steps(self, first: int, last: int, x_in, x_out) -> None:
+        check(load().fvhd_run_steps(self._h, first, last, ptr(x_in), x_in.shape[0], ptr(x_out), stream_ptr(x_in.device)),
+              "fvhd_run_steps")
 
     # ---- measurement ----
     def profile_enable(self, on: bool) -> None:

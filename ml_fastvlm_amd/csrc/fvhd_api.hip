@@ -94,7 +94,13 @@ struct RepBlockW { DwW mixer; FfnW ffn; };
 struct AttnBlockW { size_t ln_w = 0, ln_b = 0, ls1 = 0; GemmW qkv, proj; FfnW ffn; };
 struct DownW { DwW dw; GemmW pw; };
 
+// One "step" = one forward() of a reference module on the running activation (execution order of
+// FastViT.forward, mci.py:1427-1451): stem, then per stage [RepCPE], blocks, [PatchEmbed], then conv_exp+SE.
+enum StepKind { S_STEM, S_CPE, S_REP, S_ATT, S_DOWN, S_HEAD };
+struct Step { int kind, stage, idx, C, hdiv, Cout, hdiv_out; };   // H = R / hdiv on entry, R / hdiv_out on exit
+
 struct Model {
+    std::vector<Step> steps;
     size_t stem0_w = 0, stem0_b = 0;
     DwW stem1;
     GemmW stem2;
@@ -346,80 +352,86 @@ int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, in
     return run_gemm(c, st, C_FC2, c->wdev, f.fc2, w.H, c->wp<float>(f.ls), x, x, M, FVHD_EPI_BIAS_LS_RESID);
 }
 
-int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out, int out_dtype, hipStream_t st)
+int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X, char*& T, int B, const void* images,
+             int img_dtype, void* out, int out_dtype)
 {
-    if (!c->finalized) return fail("fvhd_encode: weights not finalized (call fvhd_finalize_weights)");
-    if (B <= 0) return fail("fvhd_encode: batch must be positive");
-    if (img_dtype < 0 || img_dtype > 2 || out_dtype < 0 || out_dtype > 2) return fail("fvhd_encode: bad dtype");
+    const Model& m = c->m;
+    const int R = c->R, H = R / sp.hdiv, C = sp.C, M = B * H * H;
+    int e;
+    switch (sp.kind) {
+    case S_STEM: {   // convolutional_stem (mci.py:553-603)
+        {
+            Scope s(c, st, C_STEM);
+            CHECK_LAUNCH(fvhd_launch_stem_conv(st, images, img_dtype, w.H, c->wp<float>(m.stem0_w), c->wp<float>(m.stem0_b), B, R),
+                         "stem conv launch");
+        }
+        if ((e = run_dw(c, st, C_STEM, m.stem1, w.H, w.A, B, R / 2, R / 2, 96, 2, 1, 1))) return e;
+        return run_gemm(c, st, C_STEM, c->wdev, m.stem2, w.A, nullptr, nullptr, X, B * (R / 4) * (R / 4), FVHD_EPI_BIAS_GELU);
+    }
+    case S_CPE:      // RepCPE (mci.py:992-995)
+        if ((e = run_dw(c, st, C_DW7, m.cpe[sp.stage - 3], X, T, B, H, H, C, 1, 1, 0))) return e;
+        std::swap(X, T);
+        return 0;
+    case S_REP: {    // RepMixerBlock (mci.py:1106-1109)
+        const RepBlockW& blk = m.rep[sp.stage][sp.idx];
+        if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0))) return e;
+        std::swap(X, T);
+        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C);
+    }
+    case S_ATT: {    // AttentionBlock (mci.py:1185-1188)
+        const AttnBlockW& blk = m.att[sp.stage - 3][sp.idx];
+        {
+            Scope s(c, st, C_LN);
+            CHECK_LAUNCH(fvhd_launch_layernorm(st, X, w.A, c->wp<float>(blk.ln_w), c->wp<float>(blk.ln_b), M, C, kLnEps),
+                         "layernorm launch");
+        }
+        if ((e = run_gemm(c, st, C_QKV, c->wdev, blk.qkv, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_NONE))) return e;
+        {
+            Scope s(c, st, C_ATT);
+            CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C), "attention launch");
+        }
+        if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID))) return e;
+        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C);
+    }
+    case S_DOWN: {   // PatchEmbed (mci.py:739-741)
+        const DownW& d = m.down[sp.stage];
+        if ((e = run_dw(c, st, C_DWDOWN, d.dw, X, T, B, H, H, C, 2, 2, 1))) return e;
+        return run_gemm(c, st, C_1X1, c->wdev, d.pw, T, nullptr, nullptr, X, B * (H / 2) * (H / 2), FVHD_EPI_BIAS_GELU);
+    }
+    case S_HEAD: {   // conv_exp (mci.py:1401-1411, 1444) + feature_select (mobileclip_encoder.py:60-68)
+        if ((e = run_dw(c, st, C_HEAD, m.conv_exp, X, T, B, H, H, C, 1, 2, 0))) return e;
+        Scope s(c, st, C_HEAD);
+        CHECK_LAUNCH(fvhd_launch_se_head(st, T, w.pooled, w.scale, c->wp<float>(m.se_wr), c->wp<float>(m.se_br),
+                                         c->wp<float>(m.se_we), c->wp<float>(m.se_be), out, out_dtype, B, H * H, kOutDim, kSeRd),
+                     "se head launch");
+        return 0;
+    }
+    }
+    return fail("run_step: bad step kind");
+}
+
+int prepare(fvhd_ctx* c, int B)
+{
+    if (!c->finalized) return fail("fvhd: weights not finalized (call fvhd_finalize_weights)");
+    if (B <= 0) return fail("fvhd: batch must be positive");
     int dev = -1;
     (void)hipGetDevice(&dev);
     if (dev != c->device) {
         hipError_t he = hipSetDevice(c->device);
         if (he != hipSuccess) return hip_fail("hipSetDevice", he);
     }
-    int e = ensure_ws(c, B);
+    return ensure_ws(c, B);
+}
+
+int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out, int out_dtype, hipStream_t st)
+{
+    if (img_dtype < 0 || img_dtype > 2 || out_dtype < 0 || out_dtype > 2) return fail("fvhd_encode: bad dtype");
+    int e = prepare(c, B);
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
-    const Model& m = c->m;
-    const int R = c->R;
     char *X = w.X, *T = w.T;
-
-    // ---- convolutional_stem (mci.py:553-603) ----
-    {
-        Scope s(c, st, C_STEM);
-        CHECK_LAUNCH(fvhd_launch_stem_conv(st, images, img_dtype, w.H, c->wp<float>(m.stem0_w), c->wp<float>(m.stem0_b), B, R),
-                     "stem conv launch");
-    }
-    if ((e = run_dw(c, st, C_STEM, m.stem1, w.H, w.A, B, R / 2, R / 2, 96, 2, 1, 1))) return e;
-    int H = R / 4, C = kDims[0];
-    if ((e = run_gemm(c, st, C_STEM, c->wdev, m.stem2, w.A, nullptr, nullptr, X, B * H * H, FVHD_EPI_BIAS_GELU))) return e;
-
-    // ---- network (mci.py:1431-1434; construction order mci.py:1361-1399) ----
-    for (int sIdx = 0; sIdx < kStages; ++sIdx) {
-        C = kDims[sIdx];
-        const int M = B * H * H;
-        if (sIdx >= 3) {   // RepCPE (mci.py:992-995)
-            if ((e = run_dw(c, st, C_DW7, m.cpe[sIdx - 3], X, T, B, H, H, C, 1, 1, 0))) return e;
-            std::swap(X, T);
-        }
-        if (sIdx < 3) {
-            for (const RepBlockW& blk : m.rep[sIdx]) {                       // RepMixerBlock (mci.py:1106-1109)
-                if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0))) return e;
-                std::swap(X, T);
-                if ((e = run_ffn(c, st, blk.ffn, w, X, B, H, H, C))) return e;
-            }
-        } else {
-            for (const AttnBlockW& blk : m.att[sIdx - 3]) {                  // AttentionBlock (mci.py:1185-1188)
-                {
-                    Scope s(c, st, C_LN);
-                    CHECK_LAUNCH(fvhd_launch_layernorm(st, X, w.A, c->wp<float>(blk.ln_w), c->wp<float>(blk.ln_b), M, C, kLnEps),
-                                 "layernorm launch");
-                }
-                if ((e = run_gemm(c, st, C_QKV, c->wdev, blk.qkv, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_NONE))) return e;
-                {
-                    Scope s(c, st, C_ATT);
-                    CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C), "attention launch");
-                }
-                if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID))) return e;
-                if ((e = run_ffn(c, st, blk.ffn, w, X, B, H, H, C))) return e;
-            }
-        }
-        if (sIdx < kStages - 1) {   // PatchEmbed (mci.py:739-741)
-            const DownW& d = m.down[sIdx];
-            if ((e = run_dw(c, st, C_DWDOWN, d.dw, X, T, B, H, H, C, 2, 2, 1))) return e;
-            H /= 2;
-            if ((e = run_gemm(c, st, C_1X1, c->wdev, d.pw, T, nullptr, nullptr, X, B * H * H, FVHD_EPI_BIAS_GELU))) return e;
-        }
-    }
-
-    // ---- conv_exp (mci.py:1401-1411, 1444) + feature_select (mobileclip_encoder.py:60-68) ----
-    if ((e = run_dw(c, st, C_HEAD, m.conv_exp, X, T, B, H, H, kDims[4], 1, 2, 0))) return e;
-    {
-        Scope s(c, st, C_HEAD);
-        CHECK_LAUNCH(fvhd_launch_se_head(st, T, w.pooled, w.scale, c->wp<float>(m.se_wr), c->wp<float>(m.se_br),
-                                         c->wp<float>(m.se_we), c->wp<float>(m.se_be), out, out_dtype, B, H * H, kOutDim, kSeRd),
-                     "se head launch");
-    }
+    for (const Step& sp : c->m.steps)
+        if ((e = run_step(c, st, sp, w, X, T, B, images, img_dtype, out, out_dtype))) return e;
     return 0;
 }
 
@@ -551,6 +563,14 @@ int fvhd_finalize_weights(fvhd_ctx* c)
     if (!pack_vec(c, pk, "conv_exp.se.expand.weight", {kOutDim, kSeRd, 1, 1}, &m.se_we)) return 1;
     if (!pack_vec(c, pk, "conv_exp.se.expand.bias", {kOutDim}, &m.se_be)) return 1;
     // head.proj (GlobalPool2D, mci.py:1290-1302) is dead on this path: feature_select drops the logits.
+    // ---- step list ----
+    m.steps.push_back(Step{S_STEM, 0, 0, 3, 1, kDims[0], 4});
+    for (int s = 0, hd = 4; s < kStages; ++s, hd *= 2) {
+        if (s >= 3) m.steps.push_back(Step{S_CPE, s, 0, kDims[s], hd, kDims[s], hd});
+        for (int b = 0; b < kLayers[s]; ++b) m.steps.push_back(Step{s < 3 ? S_REP : S_ATT, s, b, kDims[s], hd, kDims[s], hd});
+        if (s < kStages - 1) m.steps.push_back(Step{S_DOWN, s, 0, kDims[s], hd, kDims[s + 1], hd * 2});
+        else m.steps.push_back(Step{S_HEAD, s, 0, kDims[s], hd, kOutDim, hd});
+    }
 
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return hip_fail("hipSetDevice", e);
@@ -616,6 +636,50 @@ int fvhd_encode_images(fvhd_ctx* c, const void* images, int img_dtype, int batch
     e = encode_impl(c, images, img_dtype, batch, w.tok, FVHD_BF16, (hipStream_t)stream);
     if (e) return e;
     return project_impl(c, w.tok, FVHD_BF16, batch * fvhd_num_tokens(c), out, out_dtype, (hipStream_t)stream, w);
+}
+
+int fvhd_num_steps(const fvhd_ctx* c) { return (c && c->finalized) ? (int)c->m.steps.size() : 0; }
+
+int fvhd_step_info(const fvhd_ctx* c, int step, int* kind, int* stage, int* block, int* c_in, int* h_in, int* c_out, int* h_out)
+{
+    if (!c || !c->finalized) return fail("fvhd_step_info: weights not finalized");
+    if (step < 0 || step >= (int)c->m.steps.size()) return fail("fvhd_step_info: bad step index");
+    const Step& sp = c->m.steps[step];
+    if (kind) *kind = sp.kind;
+    if (stage) *stage = sp.stage;
+    if (block) *block = sp.idx;
+    if (c_in) *c_in = sp.C;
+    if (h_in) *h_in = c->R / sp.hdiv;
+    if (c_out) *c_out = sp.Cout;
+    if (h_out) *h_out = c->R / sp.hdiv_out;
+    return 0;
+}
+
+int fvhd_run_steps(fvhd_ctx* c, int first, int last, const void* x_in, int batch, void* x_out, fvhd_stream_t stream)
+{
+    if (!c || !x_in || !x_out) return fail("fvhd_run_steps: NULL argument");
+    int e = prepare(c, batch);
+    if (e) return e;
+    const int n = (int)c->m.steps.size();
+    if (first < 0 || last >= n || first > last) return fail("fvhd_run_steps: bad step range");
+    hipStream_t st = (hipStream_t)stream;
+    const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
+    char *X = w.X, *T = w.T;
+    const Step& s0 = c->m.steps[first];
+    const Step& s1 = c->m.steps[last];
+    if (s0.kind != S_STEM) {
+        const size_t hin = (size_t)(c->R / s0.hdiv);
+        hipError_t he = hipMemcpyAsync(X, x_in, (size_t)batch * hin * hin * s0.C * 2, hipMemcpyDeviceToDevice, st);
+        if (he != hipSuccess) return hip_fail("hipMemcpyAsync(x_in)", he);
+    }
+    for (int i = first; i <= last; ++i)
+        if ((e = run_step(c, st, c->m.steps[i], w, X, T, batch, x_in, FVHD_BF16, x_out, FVHD_BF16))) return e;
+    if (s1.kind != S_HEAD) {
+        const size_t hout = (size_t)(c->R / s1.hdiv_out);
+        hipError_t he = hipMemcpyAsync(x_out, X, (size_t)batch * hout * hout * s1.Cout * 2, hipMemcpyDeviceToDevice, st);
+        if (he != hipSuccess) return hip_fail("hipMemcpyAsync(x_out)", he);
+    }
+    return 0;
 }
 
 int fvhd_num_tokens(const fvhd_ctx* c) { return c ? (c->R / 64) * (c->R / 64) : 0; }

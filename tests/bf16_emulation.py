@@ -48,49 +48,80 @@ def _attention(n, p, pre):
     return rb(o.transpose(1, 2).reshape(B, N, C))         # attention output stored bf16
 
 
-def emulate_tower(images, p, img_dtype=torch.bfloat16, out_dtype=torch.bfloat16):
+def step_fns(p):
+    """[(name, fn)] in the library's step order (include/fvhd.h "step-level execution"): fn maps the NCHW fp32
+    (bf16-representable) activation entering the step to the one leaving it, rounded where the HIP path stores.
+    Step 0 takes the image batch; the last step returns [B, T, 3072] tokens (fp32 values, not yet rounded)."""
     p = {k: v.float() for k, v in p.items() if v.is_floating_point()}
-    with torch.no_grad():
-        x = images.to(img_dtype).float()
+    steps = []
+
+    def stem(x):
         x = rb(O.gelu(F.conv2d(x, p["patch_embed.0.reparam_conv.weight"], p["patch_embed.0.reparam_conv.bias"], stride=2, padding=1)))
         x = rb(O.gelu(F.conv2d(x, p["patch_embed.1.reparam_conv.weight"], p["patch_embed.1.reparam_conv.bias"], stride=2, padding=1, groups=96)))
-        x = rb(O.gelu(F.conv2d(x, rb(p["patch_embed.2.reparam_conv.weight"]), p["patch_embed.2.reparam_conv.bias"])))
-        idx = 0
-        for i in range(5):
-            C = DIMS[i]
-            if i >= 3:
-                pre = f"network.{idx}"
-                x = rb(F.conv2d(x, p[f"{pre}.reparam_conv.weight"], p[f"{pre}.reparam_conv.bias"], padding=3, groups=C))
-                idx += 1
-            for b in range(LAYERS[i]):
-                pre = f"network.{idx}.{b}"
-                if i < 3:
-                    t = rb(F.conv2d(x, p[f"{pre}.token_mixer.reparam_conv.weight"], p[f"{pre}.token_mixer.reparam_conv.bias"],
-                                    padding=1, groups=C))
-                    x = _ffn(t, p, f"{pre}.convffn", p[f"{pre}.layer_scale"])
-                else:
-                    n = rb(O.layernorm_channel(x, p[f"{pre}.norm.weight"], p[f"{pre}.norm.bias"]))
-                    o = _attention(n, p, f"{pre}.token_mixer")
-                    B_, _, H_, W_ = x.shape
-                    y = F.linear(o, rb(p[f"{pre}.token_mixer.proj.weight"]), p[f"{pre}.token_mixer.proj.bias"])
-                    y = y.transpose(1, 2).reshape(B_, C, H_, W_)
-                    x = rb(x + p[f"{pre}.layer_scale_1"] * y)
-                    x = _ffn(x, p, f"{pre}.convffn", p[f"{pre}.layer_scale_2"])
-            idx += 1
-            if i == 4:
-                break
-            pre = f"network.{idx}"
+        return rb(O.gelu(F.conv2d(x, rb(p["patch_embed.2.reparam_conv.weight"]), p["patch_embed.2.reparam_conv.bias"])))
+
+    def cpe(pre, C):
+        return lambda x: rb(F.conv2d(x, p[f"{pre}.reparam_conv.weight"], p[f"{pre}.reparam_conv.bias"], padding=3, groups=C))
+
+    def rep(pre, C):
+        def f(x):
+            t = rb(F.conv2d(x, p[f"{pre}.token_mixer.reparam_conv.weight"], p[f"{pre}.token_mixer.reparam_conv.bias"],
+                            padding=1, groups=C))
+            return _ffn(t, p, f"{pre}.convffn", p[f"{pre}.layer_scale"])
+        return f
+
+    def att(pre, C):
+        def f(x):
+            n = rb(O.layernorm_channel(x, p[f"{pre}.norm.weight"], p[f"{pre}.norm.bias"]))
+            o = _attention(n, p, f"{pre}.token_mixer")
+            B_, _, H_, W_ = x.shape
+            y = F.linear(o, rb(p[f"{pre}.token_mixer.proj.weight"]), p[f"{pre}.token_mixer.proj.bias"])
+            y = y.transpose(1, 2).reshape(B_, C, H_, W_)
+            x = rb(x + p[f"{pre}.layer_scale_1"] * y)
+            return _ffn(x, p, f"{pre}.convffn", p[f"{pre}.layer_scale_2"])
+        return f
+
+    def down(pre, C):
+        def f(x):
             y = rb(O.gelu(F.conv2d(x, p[f"{pre}.proj.0.lkb_reparam.weight"], p[f"{pre}.proj.0.lkb_reparam.bias"],
                                    stride=2, padding=3, groups=C)))
-            x = rb(O.gelu(F.conv2d(y, rb(p[f"{pre}.proj.1.reparam_conv.weight"]), p[f"{pre}.proj.1.reparam_conv.bias"])))
-            idx += 1
+            return rb(O.gelu(F.conv2d(y, rb(p[f"{pre}.proj.1.reparam_conv.weight"]), p[f"{pre}.proj.1.reparam_conv.bias"])))
+        return f
+
+    def head(x):
         y = rb(F.conv2d(x, p["conv_exp.reparam_conv.weight"], p["conv_exp.reparam_conv.bias"], padding=1, groups=DIMS[4]))
         s = y.mean((2, 3), keepdim=True)
         s = F.relu(F.conv2d(s, p["conv_exp.se.reduce.weight"], p["conv_exp.se.reduce.bias"]))
         s = torch.sigmoid(F.conv2d(s, p["conv_exp.se.expand.weight"], p["conv_exp.se.expand.bias"]))
         f = O.gelu(y * s)
         B_, C_, H_, W_ = f.shape
-        return f.reshape(B_, C_, H_ * W_).transpose(1, 2).to(out_dtype)
+        return f.reshape(B_, C_, H_ * W_).transpose(1, 2)
+
+    steps.append(("stem", stem))
+    idx = 0
+    for i in range(5):
+        C = DIMS[i]
+        if i >= 3:
+            steps.append((f"network.{idx} (RepCPE)", cpe(f"network.{idx}", C)))
+            idx += 1
+        for b in range(LAYERS[i]):
+            pre = f"network.{idx}.{b}"
+            steps.append((pre, rep(pre, C) if i < 3 else att(pre, C)))
+        idx += 1
+        if i == 4:
+            break
+        steps.append((f"network.{idx} (PatchEmbed)", down(f"network.{idx}", C)))
+        idx += 1
+    steps.append(("conv_exp", head))
+    return steps
+
+
+def emulate_tower(images, p, img_dtype=torch.bfloat16, out_dtype=torch.bfloat16):
+    with torch.no_grad():
+        x = images.to(img_dtype).float()
+        for _, fn in step_fns(p):
+            x = fn(x)
+        return x.to(out_dtype)
 
 
 def emulate_projector(tokens_bf16, pj, out_dtype=torch.bfloat16):
