@@ -130,12 +130,15 @@ int fvhd_op_se_head(fvhd_stream_t stream, const void* y, float* pooled, float* s
                     const float* we, const float* be, void* out, int out_dtype, int B, int T, int C, int RD);
 
 /* Fused ConvFFN MLP (mci.py:922-926 + 1106-1109): X <- X + ls * (gelu(A.W1^T + b1).W2^T + b2), in place on X [M,C] bf16.
- * C in {96,192,384}.  A [M,C] bf16; W1 bf16 [4C][C]; b1 fp32 [4C]; b2, ls fp32 [C];
- * W2s = fc2 weight [C][4C] repacked slice-major [4C/HS][C][HS], HS = fvhd_ffn_slice(C), with the hidden axis permuted
- * inside every 32-chunk: position 16kb+8half+j holds hidden unit 16kb+8(j>>2)+4half+(j&3)  (kb,half in {0,1}, j in 0..7). */
-int fvhd_op_ffn_fused(fvhd_stream_t stream, const void* A, const void* W1, const float* b1, const void* W2s,
+ * C in {96,192,384} (fvhd_ffn_fused_supported).  A [M,C] bf16; b1 fp32 [4C]; b2, ls fp32 [C];
+ * w1img / w2img: DEVICE copies of the bf16 chunk images fvhd_ffn_pack writes on the host from fc1.weight [4C][C] and
+ * fc2.weight [C][4C] (fp32, the reference's layouts): per chunk of 32 hidden units a 64*C-byte image in the kernel's
+ * LDS byte order (XOR-swizzled 16-B slots; fc2's hidden axis permuted inside the chunk so that position 16kb+8half+j
+ * holds hidden unit 16kb+8(j>>2)+4half+(j&3)).  Sizes: w1img (4C/32 + 1) * 64*C bytes (last chunk zero), w2img 4C/32 * 64*C. */
+int fvhd_ffn_fused_supported(int C);
+int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img);
+int fvhd_op_ffn_fused(fvhd_stream_t stream, const void* A, const void* w1img, const float* b1, const void* w2img,
                       const float* b2, const float* ls, void* X, int M, int C);
-int fvhd_ffn_slice(int C);
 
 #ifdef __cplusplus
 }

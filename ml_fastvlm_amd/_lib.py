@@ -49,7 +49,8 @@ def _declare(lib) -> None:
         "fvhd_op_stem_conv": (ci, [vp, vp, ci, vp, vp, vp, ci, ci]),
         "fvhd_op_se_head": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
         "fvhd_op_ffn_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci]),
-        "fvhd_ffn_slice": (ci, [ci]),
+        "fvhd_ffn_fused_supported": (ci, [ci]),
+        "fvhd_ffn_pack": (ci, [ci, vp, vp, vp, vp]),
     }
     del fp, cl
     for name, (res, args) in sig.items():

@@ -20,6 +20,14 @@ SOURCES = ["dwconv.hip", "gemm.hip", "attention.hip", "stem_head.hip", "ffn_fuse
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-fno-gpu-rdc"]
+# Per-file extras.  ffn_fused.hip: packed fp32 VALU (v_pk_*) beside MFMAs is slower than the scalar forms and loses the
+# |x| / -x operand modifiers (MI355X_MICROARCH "price of one filler beside MFMAs"), so the SLP vectoriser stays off there.
+# Everywhere else it stays ON: a wave64 VALU instruction issues every ~4 cycles packed or not, so v_pk_fma_f32 halves the
+# instruction count of the VALU-bound depthwise kernels (measured: 588 -> 380 instructions per tap row of the dw7x7).
+# -pragma-unroll-threshold: the 48-slot software pipeline of ffn_fused.hip must be FULLY unrolled (all register-array
+# indices compile-time); above the default 16 K-instruction threshold LLVM silently keeps a loop and the accumulators
+# land in scratch (2.7 KB/lane).
+EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 def _hipcc() -> str:
@@ -49,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(BUILD, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

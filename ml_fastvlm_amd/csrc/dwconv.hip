@@ -136,34 +136,51 @@ static hipError_t launch_dw(hipStream_t st, const bf16* x, bf16* y, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------
-// LDS-tiled stride-1 depthwise conv (K = 3 or 7, multiplier 1): the hot variant - 38 dw3x3 + 46 dw7x7
-// launches per forward.  A workgroup owns a TH x 16 output tile of one CS-channel slice:
-//   * the (TH+K-1) x (16+K-1) input tile (zero padded at the image border) is staged ONCE into LDS with
-//     16-B-per-lane coalesced loads; the K*K re-reads per output then hit LDS (256 B/clk/CU) instead of
-//     the vector L1 (64 B/clk/CU), which is what bound the direct-load kernel (708 GB/s on dw7x7);
-//   * the LDS row stride is an ODD number of pixels so that vertically adjacent strips of a wave fall in
-//     different 128-B bank halves;
-//   * each lane computes 8 channels x a strip of 8 output pixels, re-using every LDS vector for up to K
-//     outputs and every tap (fp32, read from LDS once per row) for 8 outputs;
-//   * tiles are ordered (slice fastest, then x, y, image) inside one 1-D grid and XCD-remapped, so the
-//     CS-channel slices of a pixel (same 128-B lines when C = 96) and the halo-sharing neighbours run on
-//     the same XCD / L2.
-template <int K, int CS>
+// LDS-tiled depthwise conv - the hot variant (38 dw3x3 + 46 dw7x7 + 4 dw7x7/s2 + the stem's dw3x3/s2 per forward).
+// A workgroup owns a TH x TW output tile of one CS-output-channel slice:
+//   * the ((TH-1)S+K) x ((TW-1)S+K) input tile (zero padded at the image border) is staged ONCE into LDS.  Every
+//     thread first ISSUES all of its 16-B global loads (compile-time trip count, fully unrolled: 13-18 independent
+//     loads in flight per lane) and only then writes them to LDS - the round-1 version walked the tile with a
+//     load -> ds_write -> next-load loop, i.e. ~15 dependent HBM round trips per tile, and ran at 1.1-1.3 TB/s;
+//   * the K*K re-reads per output then hit LDS (256 B/clk/CU) instead of the vector L1 (64 B/clk/CU);
+//   * the LDS row stride is an ODD number of pixels so that vertically adjacent strips of a wave fall in different
+//     128-B bank halves;
+//   * each lane computes 8 output channels x a strip of OWT output pixels, re-using every LDS vector for up to
+//     ceil(K/S) outputs and every tap (fp32, read from LDS once per tap row) for OWT outputs;
+//   * tiles are ordered (slice fastest, then x, y, image) inside one 1-D grid and XCD-remapped, so the channel slices
+//     of a pixel and the halo-sharing neighbours run on the same XCD / L2: the halo re-reads (1.6-1.9x the tile) are
+//     L2 hits, HBM sees every input byte about once.
+template <int K, int S, int MULT, bool ACT, int CS>
+struct DwTile {
+    static constexpr int PAD = K / 2;
+    static constexpr int CSI = CS / MULT;            // input channels per slice
+    static constexpr int LPP = CS / 8;               // lanes per output pixel (8 output channels each)
+    static constexpr int LPI = CSI / 8;              // 16-B chunks per input pixel
+    static constexpr int NSTRIP = 256 / LPP;         // strips per workgroup
+    static constexpr int OWT = S == 1 ? 8 : 4;       // output pixels per strip
+    static constexpr int TW = 2 * OWT, TH = NSTRIP / 2;
+    static constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K;
+    static constexpr int IWP = IW | 1;               // odd row stride (pixels)
+    static constexpr int NIN = (OWT - 1) * S + K;    // input columns touched by one strip
+    static constexpr int CI = 8 / MULT;              // input channels per lane
+    static constexpr int NCHUNK = IH * IW * LPI;
+    static constexpr int NLD = (NCHUNK + 255) / 256;
+    static constexpr size_t TILE_B = (size_t)IH * IWP * CSI * 2;
+    static constexpr size_t SHMEM = TILE_B + (size_t)K * K * CS * 4;
+};
+
+template <int K, int S, int MULT, bool ACT, int CS>
 __global__ __launch_bounds__(256) void dwconv_tiled_kernel(
     const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
-    int B, int H, int W, int C, int tiles_x, int tiles_y, int nslices, int nwg)
+    int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int nwg)
 {
-    constexpr int PAD = K / 2;
-    constexpr int LPP = CS / 8;                 // lanes per pixel
-    constexpr int NSTRIP = 256 / LPP;           // strips per workgroup
-    constexpr int TW = 16, OWT = 8;
-    constexpr int TH = NSTRIP / (TW / OWT);     // 16 (CS=64) or 32 (CS=32)
-    constexpr int IW = TW + 2 * PAD, IH = TH + 2 * PAD;
-    constexpr int IWP = (IW % 2 == 0) ? IW + 1 : IW;   // odd row stride (pixels)
-    constexpr int NIN = OWT + K - 1;
+    using T = DwTile<K, S, MULT, ACT, CS>;
+    constexpr int PAD = T::PAD, CSI = T::CSI, LPP = T::LPP, LPI = T::LPI, OWT = T::OWT, TW = T::TW, TH = T::TH;
+    constexpr int IW = T::IW, IWP = T::IWP, NIN = T::NIN, CI = T::CI, NLD = T::NLD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* tile = (bf16*)smem;                                   // [IH][IWP][CS]
-    float* lw = (float*)(smem + (size_t)IH * IWP * CS * 2);     // [K*K][CS]
+    bf16* tile = (bf16*)smem;                                   // [IH][IWP][CSI]
+    float* lw = (float*)(smem + T::TILE_B);                     // [K*K][CS]
+    const int Cout = Cin * MULT;
 
     const int L = xcd_remap(blockIdx.x, nwg);
     const int slice = L % nslices;
@@ -171,38 +188,46 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = t / tiles_y;
-    const int c0 = slice * CS;
+    const int oc0 = slice * CS, ic0 = slice * CSI;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < K * K * CS / 4; i += 256) {
-        const int e = i * 4, tap = e / CS, c = e - tap * CS;
-        *(f32x4*)&lw[e] = *(const f32x4*)&w[(size_t)tap * C + c0 + c];
-    }
-    const int gy0 = ty * TH - PAD, gx0 = tx * TW - PAD;
-    for (int i = tid; i < IH * IW * LPP; i += 256) {
-        const int cgi = i % LPP, p = i / LPP;
+    // ---- stage the input tile: all loads first, then all LDS writes
+    const int gy0 = ty * TH * S - PAD, gx0 = tx * TW * S - PAD;
+    u32x4 v[NLD];
+    int dst[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = i * 256 + tid;
+        const int cgi = idx % LPI, p = idx / LPI;
         const int iy = p / IW, ix = p - iy * IW;
         const int gy = gy0 + iy, gx = gx0 + ix;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = *(const u32x4*)(x + ((size_t)(b * H + gy) * W + gx) * C + c0 + cgi * 8);
-        *(u32x4*)(tile + ((size_t)iy * IWP + ix) * CS + cgi * 8) = v;
+        v[i] = u32x4{0u, 0u, 0u, 0u};
+        dst[i] = idx < T::NCHUNK ? ((iy * IWP + ix) * CSI + cgi * 8) * 2 : -1;
+        if (idx < T::NCHUNK && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v[i] = *(const u32x4*)(x + ((size_t)(b * H + gy) * W + gx) * Cin + ic0 + cgi * 8);
     }
+    for (int i = tid; i < K * K * CS / 4; i += 256) {
+        const int e = i * 4, tap = e / CS, c = e - tap * CS;
+        *(f32x4*)&lw[e] = *(const f32x4*)&w[(size_t)tap * Cout + oc0 + c];
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+        if (dst[i] >= 0) *(u32x4*)(smem + dst[i]) = v[i];
     __syncthreads();
 
     const int cg = tid % LPP, strip = tid / LPP;
-    const int r = strip / (TW / OWT), xh = strip % (TW / OWT);
+    const int r = strip >> 1, xh = strip & 1;
     const int oy = ty * TH + r, ox0 = tx * TW + xh * OWT;
-    if (oy >= H || ox0 >= W) return;
+    if (oy >= OH || ox0 >= OW) return;
 
     float acc[OWT][8];
 #pragma unroll
     for (int o = 0; o < OWT; ++o)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[o][c] = bias ? bias[c0 + cg * 8 + c] : 0.0f;
+        for (int c = 0; c < 8; ++c) acc[o][c] = bias ? bias[oc0 + cg * 8 + c] : 0.0f;
 
 #pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {     // not unrolled: keeps the live set at acc(64) + one tap row(56) + one vector
+    for (int ky = 0; ky < K; ++ky) {     // not unrolled: keeps the live set at acc + one tap row + one vector
         float wr[K][8];
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
@@ -211,48 +236,57 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(
 #pragma unroll
             for (int c = 0; c < 4; ++c) { wr[kx][c] = w0[c]; wr[kx][4 + c] = w1[c]; }
         }
-        const bf16* row = tile + ((size_t)(r + ky) * IWP + xh * OWT) * CS + cg * 8;
+        const bf16* row = tile + ((size_t)(r * S + ky) * IWP + xh * OWT * S) * CSI + cg * CI;
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
-            const f32x8 v = bf8_to_f32(*(const bf16x8*)(row + j * CS));
+            float vv[CI];
+            if constexpr (CI == 8) {
+                const f32x8 tv = bf8_to_f32(*(const bf16x8*)(row + j * CSI));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) vv[c] = tv[c];
+            } else {
+                const f32x4 tv = bf4_to_f32(*(const bf16x4*)(row + j * CSI));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vv[c] = tv[c];
+            }
 #pragma unroll
             for (int o = 0; o < OWT; ++o) {
-                const int kx = j - o;
+                const int kx = j - o * S;
                 if (kx >= 0 && kx < K) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[o][c] = __builtin_fmaf(wr[kx][c], v[c], acc[o][c]);
+                    for (int c = 0; c < 8; ++c) acc[o][c] = __builtin_fmaf(wr[kx][c], vv[c / MULT], acc[o][c]);
                 }
             }
         }
     }
-    bf16* yo = y + ((size_t)(b * H + oy) * W + ox0) * C + c0 + cg * 8;
+    bf16* yo = y + ((size_t)(b * OH + oy) * OW + ox0) * Cout + oc0 + cg * 8;
 #pragma unroll
     for (int o = 0; o < OWT; ++o) {
-        if (ox0 + o >= W) break;
+        if (ox0 + o >= OW) break;
         f32x8 rr;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) rr[c] = acc[o][c];
-        *(bf16x8*)(yo + (size_t)o * C) = f32_to_bf8(rr);
+        for (int c = 0; c < 8; ++c) rr[c] = ACT ? gelu_erf(acc[o][c]) : acc[o][c];
+        *(bf16x8*)(yo + (size_t)o * Cout) = f32_to_bf8(rr);
     }
 }
 
-template <int K, int CS>
+template <int K, int S, int MULT, bool ACT, int CS>
 static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const float* w, const float* bias,
-                                  int B, int H, int W, int C)
+                                  int B, int H, int W, int Cin)
 {
-    constexpr int PAD = K / 2, LPP = CS / 8, TW = 16, TH = (256 / LPP) / 2;
-    constexpr int IW = TW + 2 * PAD, IH = TH + 2 * PAD, IWP = (IW % 2 == 0) ? IW + 1 : IW;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, nslices = C / CS;
+    using T = DwTile<K, S, MULT, ACT, CS>;
+    const int OH = (H + 2 * T::PAD - K) / S + 1, OW = (W + 2 * T::PAD - K) / S + 1;
+    const int tiles_x = (OW + T::TW - 1) / T::TW, tiles_y = (OH + T::TH - 1) / T::TH, nslices = Cin * MULT / CS;
     const int nwg = B * tiles_x * tiles_y * nslices;
-    const size_t shmem = (size_t)IH * IWP * CS * 2 + (size_t)K * K * CS * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwconv_tiled_kernel<K, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipError_t e = hipFuncSetAttribute((const void*)dwconv_tiled_kernel<K, S, MULT, ACT, CS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SHMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((dwconv_tiled_kernel<K, CS>), dim3(nwg), dim3(256), shmem, st, x, y, w, bias, B, H, W, C,
-                       tiles_x, tiles_y, nslices, nwg);
+    hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS>), dim3(nwg), dim3(256), T::SHMEM, st, x, y, w, bias,
+                       B, H, W, Cin, OH, OW, tiles_x, tiles_y, nslices, nwg);
     return hipGetLastError();
 }
 
@@ -262,15 +296,19 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
 {
     const bf16* xi = (const bf16*)x;
     bf16* yo = (bf16*)y;
+    const int Cout = Cin * mult;
     hipError_t e = hipErrorInvalidValue;
-    if (stride == 1 && mult == 1 && !gelu && (K == 3 || K == 7) && Cin % 32 == 0) {
-        // hot variants: LDS-tiled kernel; 64-channel slices when they divide C, else 32
-        if (Cin % 64 == 0) e = (K == 7) ? launch_dw_tiled<7, 64>(st, xi, yo, w, bias, B, H, W, Cin)
-                                        : launch_dw_tiled<3, 64>(st, xi, yo, w, bias, B, H, W, Cin);
-        else               e = (K == 7) ? launch_dw_tiled<7, 32>(st, xi, yo, w, bias, B, H, W, Cin)
-                                        : launch_dw_tiled<3, 32>(st, xi, yo, w, bias, B, H, W, Cin);
+    const bool c64 = Cout % 64 == 0, c32 = Cout % 32 == 0;
+    // hot variants: LDS-tiled kernel; 64-output-channel slices when they divide Cout, else 32
+#define DW_TILED(KK, SS, MM, AA)                                                                          \
+    if (K == KK && stride == SS && mult == MM && (gelu != 0) == AA && c32) {                              \
+        e = c64 ? launch_dw_tiled<KK, SS, MM, AA, 64>(st, xi, yo, w, bias, B, H, W, Cin)                  \
+                : launch_dw_tiled<KK, SS, MM, AA, 32>(st, xi, yo, w, bias, B, H, W, Cin);                 \
+        return (int)e;                                                                                    \
     }
-    else if (K == 3 && stride == 1 && mult == 1 && !gelu) e = launch_dw<3, 1, 1, false>(st, xi, yo, w, bias, B, H, W, Cin);
+    DW_TILED(3, 1, 1, false) DW_TILED(7, 1, 1, false) DW_TILED(7, 2, 2, true) DW_TILED(3, 2, 1, true) DW_TILED(3, 1, 2, false)
+#undef DW_TILED
+    if (K == 3 && stride == 1 && mult == 1 && !gelu) e = launch_dw<3, 1, 1, false>(st, xi, yo, w, bias, B, H, W, Cin);
     else if (K == 3 && stride == 2 && mult == 1 && gelu) e = launch_dw<3, 2, 1, true>(st, xi, yo, w, bias, B, H, W, Cin);
     else if (K == 7 && stride == 1 && mult == 1 && !gelu) e = launch_dw<7, 1, 1, false>(st, xi, yo, w, bias, B, H, W, Cin);
     else if (K == 7 && stride == 2 && mult == 2 && gelu) e = launch_dw<7, 2, 2, true>(st, xi, yo, w, bias, B, H, W, Cin);

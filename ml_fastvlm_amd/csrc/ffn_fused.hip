@@ -4,211 +4,395 @@
 //   A is the output of the (BatchNorm-folded) depthwise 7x7 (mci.py:921).
 //
 // 94 % of the encoder's FLOPs are these two 1x1 GEMMs.  Run as two kernels, the [M, 4C] hidden tensor
-// makes stages 0-1 HBM-bound (arithmetic intensity 77 / 154 flop/B) and its bias+erf-GELU epilogue is
-// as long as the GEMM main loop at K = C <= 384 (round-1 profile: fc1 260-396 TF/s).  Here the hidden
-// activations never leave the register file ("flash-MLP", the same operand trick as the attention
-// kernel):
+// makes stages 0-1 HBM-bound and its bias + erf-GELU epilogue is as long as the GEMM main loop at
+// K = C <= 384.  Here the hidden activations never leave the register file ("flash-MLP"):
 //
-//   * a wave owns 32 rows (pixels) of A for the whole kernel; the row block A^T lives in registers as
-//     the B operands of v_mfma_f32_32x32x16_bf16 (C/16 fragments), the output block O^T[C x 32] as
-//     C/32 fp32 accumulator tiles (AGPRs).
-//   * per 32 hidden units: S^T[32h x 32m] = W1chunk . A^T  (C/16 MFMAs, W1 fragment = A operand read
-//     from LDS) -> + b1, exact-erf GELU in fp32 -> round to bf16.  The C/D layout leaves lane
-//     (m = lane&31, half = lane>>5) with the 16 hidden units h = (r&3) + 8(r>>2) + 4*half; regs 0-7 /
-//     8-15 are, as they stand, valid B operands of the two K=16 steps of O^T += W2chunk . P^T for the
-//     hidden order  k-slot (half, j) <-> h = 16kb + 8(j>>2) + 4half + (j&3).  W2 is stored by the host
-//     with its hidden axis pre-permuted into exactly that order (fvhd_api.hip: pack_ffn), so the W2
-//     fragment is a plain 16-B ds_read_b128 and P needs no cross-lane movement and no LDS round trip.
-//   * W1 / W2 stream through LDS in slices of HS hidden units (24 KB each), shared by the 4 waves of
-//     a workgroup, double buffered: the next slice's global loads are issued before the current
-//     slice's MFMAs and written to the other buffer after them; one barrier per slice.
-//     16-B slot XOR swizzles (per row stride) make the ds_write_b128 and the fragment ds_read_b128
-//     conflict-free (lane groups of MI355X_MICROARCH "LDS").
+//   * a wave owns NB blocks of 32 rows (pixels) for the whole kernel; the row block A^T lives in
+//     registers as the B operands of v_mfma_f32_32x32x16_bf16 (C/16 fragments per block), the output
+//     block O^T[C x 32] as C/32 fp32 accumulator tiles per block.
+//   * per chunk of 32 hidden units: S^T[32h x 32m] = W1chunk . A^T (C/16 MFMAs, accumulator pre-loaded
+//     with b1) -> exact-erf GELU in fp32 -> bf16.  The C/D layout leaves lane (m = lane&31, half =
+//     lane>>5) with hidden units h = (r&3) + 8(r>>2) + 4*half; regs 0-7 / 8-15 are, as they stand, the
+//     B operands of the two K=16 steps of O^T += W2chunk . P^T for the hidden order
+//     k-slot (kb, half, j) <-> h = 16kb + 8(j>>2) + 4half + (j&3).  The host stores W2 with its hidden
+//     axis pre-permuted into exactly that order, so P needs no cross-lane movement and no LDS trip.
+//   * software pipeline, skewed by two chunks, so that the VALU work of the GELU runs in the issue
+//     shadow of MFMAs that do not depend on it:   iteration t issues
+//         GEMM1(chunk t)  ||  GELU(chunk t-1)  ||  GEMM2(chunk t-2).
+//   * W1 / W2 chunk images (64*C bytes each) are pre-swizzled on the host into the exact byte order the
+//     LDS wants (16-B slot XOR swizzles that make the fragment ds_read_b128 conflict-free for the lane
+//     groups of MI355X_MICROARCH "LDS"), so staging is a linear LDS-DMA copy
+//     (global_load_lds_dwordx4: no VGPRs, no ds_write pass), double buffered per matrix, issued one
+//     iteration ahead; one barrier per chunk.
+//   * 4 waves x 32 rows per workgroup.  C = 384: one workgroup per CU (496 VGPR+AGPR per lane: the register file is the
+//     accumulators);  C = 192 / 96: <= 256 registers, two workgroups per CU, so that one workgroup's HBM-bound prologue
+//     (A^T rows) and epilogue (residual read-modify-write of X) - 40-48 % of the kernel time at these sizes (round-1
+//     ablation) - overlaps the other's MFMA loop.  NB = 2 row blocks per wave (every LDS fragment feeds two MFMAs) is
+//     implemented but measured no faster: the kernel is not LDS-bandwidth-bound at these sizes.
 //   * HBM traffic per row: A in (2C B), X in/out (4C B) - the algorithmic minimum; weights come from L2.
 #include "fvhd_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int C> FVHD_DEV int w1_off(int row, int slot)      // W1 slice [HS][C] bf16, slot = 16-B index in the row
+template <int C> __host__ __device__ __forceinline__ int w1_off(int row, int slot)      // W1 chunk [32][C] bf16, slot = 16-B index in the row
 {
     if constexpr (C == 384) return row * 768 + ((slot ^ (row & 15)) << 4);
     else if constexpr (C == 192) return row * 384 + ((slot ^ ((row >> 1) & 7)) << 4);
     else return row * 192 + ((slot ^ ((row >> 2) & 3)) << 4);            // C == 96
 }
 
-template <int HS> FVHD_DEV int w2_off(int row, int slot)     // W2 slice [C][HS] bf16
+__host__ __device__ __forceinline__ int w2_off(int row, int slot)                        // W2 chunk [C][32] bf16 (64-B rows)
 {
-    if constexpr (HS == 32) return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-    else if constexpr (HS == 64) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
-    else return row * 256 + ((slot ^ (row & 15)) << 4);                   // HS == 128
+    return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
 }
 
-template <int C, int HS, int OCC>
-__global__ __launch_bounds__(256, OCC) void ffn_fused_kernel(
-    const bf16* __restrict__ A, const bf16* __restrict__ W1, const float* __restrict__ b1,
-    const bf16* __restrict__ W2s, const float* __restrict__ b2, const float* __restrict__ ls,
+// exact-erf GELU, 14 VALU issue slots, cut into six half-stages of 2-3 VALU; the software pipeline below advances two
+// hidden values (independent dependency chains) by one half-stage per MFMA slot:
+//   gelu(x) = max(x, 0) - |x| * Phi(-|x|),   Phi(-|x|) = 0.5 erfc(|x| / sqrt 2)  (A&S 7.1.26, |err| <= 1.5e-7)
+struct GeluSt { float x, u, t, z, q, e; };
+template <int H> FVHD_DEV void gelu_half(GeluSt& g, float s, float b, float& out)
+{
+    if constexpr (H == 0) { g.x = s + b; g.u = __builtin_fmaf(0.3275911f * 0.70710678118654752f, fabsf(g.x), 1.0f); }
+    else if constexpr (H == 1) { g.t = __builtin_amdgcn_rcpf(g.u); g.z = (g.x * -0.72134752044448170f) * g.x; }   // z = -x^2/2 * log2(e)
+    else if constexpr (H == 2) { g.e = __builtin_amdgcn_exp2f(g.z); g.q = __builtin_fmaf(0.5f * 1.061405429f, g.t, 0.5f * -1.453152027f); }
+    else if constexpr (H == 3) { g.q = __builtin_fmaf(g.q, g.t, 0.5f * 1.421413741f); g.q = __builtin_fmaf(g.q, g.t, 0.5f * -0.284496736f); }
+    else if constexpr (H == 4) { g.q = __builtin_fmaf(g.q, g.t, 0.5f * 0.254829592f); g.q = g.q * g.t; }
+    else {
+        const float h = g.q * g.e;                          // Phi(-|x|)
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(g.x));    // relu without the canonicalising self-max fmaxf() costs
+        out = __builtin_fmaf(-fabsf(g.x), h, r);
+    }
+}
+
+// 16 B/lane LDS-DMA (global -> LDS, no VGPR staging): LDS destination = wave-uniform byte address `lds_dst` + lane*16.
+// Issued from inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc's waitcnt pass
+// degrades every counted lgkmcnt(N) of the fragment ds_reads to lgkmcnt(0) (measured: 96 counted waits without the
+// builtin, 0 with it), which exposes the full LDS latency before every MFMA.  hipcc does not count an asm load, so the
+// consumer side waits explicitly: s_waitcnt vmcnt(0) before the barrier that publishes the images (ffn_wait_dma).
+// M0 is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md 5.7).
+FVHD_DEV void glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+FVHD_DEV void ffn_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+FVHD_DEV unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+
+// One pipeline iteration t, for the NB 32-row blocks a wave owns:
+//     s_out <- GEMM1(chunk t);   p_out <- GELU(s_in + b1 = S(t-1));   O += GEMM2(chunk t-2, p_in = P(t-2)).
+// The iteration is cut into NM = 2*KS*NB slots of one MFMA each.  Fragment f (f even: W1 k-step f/2, f odd: W2 fragment
+// f/2) is read from LDS once and feeds NB consecutive slots (one per row block), so consecutive MFMAs never share an
+// accumulator, and the instruction order is pinned slot by slot with sched_barrier:
+//     slot m = { MFMA m | LDS fragment read (PF fragments ahead) | one 1-KiB LDS-DMA piece of next iteration's weights
+//                (some slots) | 96*NB/NM GELU half-stages (2-3 VALU each, from independent dependency chains) }
+// i.e. every 32-cycle MFMA carries a handful of independent single-issue fillers - what one wave can issue in its shadow
+// (MI355X_MICROARCH "one wave per SIMD") - instead of 200+ VALU in a lump between two MFMA bursts.
+template <int C, int NB, int WAVES, bool DO_A, bool DO_B, bool DO_C, bool DO_DMA, int VAR, int PF>
+FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32], f32x16 (&s_out)[NB], const f32x16 (&s_in)[NB],
+                       bf16x8 (&p_out)[NB][2], const bf16x8 (&p_in)[NB][2], const char* const (&w1p)[C / 48],
+                       const char* const (&w2p)[2], const int ring, const float* b1_prev, int half,
+                       const char* dma_src1, unsigned dma_dst1, bool dma1, const char* dma_src2, unsigned dma_dst2, bool dma2, int uwave)
+{
+    constexpr int KS = C / 16, NF = 2 * KS, NM = NF * NB;   // fragments, MFMA slots
+    constexpr int NA = C / 48, CHB = 64 * C, NG = CHB / 1024;
+    constexpr int UPS = 96 * NB / NM;       // GELU half-stage units per slot (16 values x 6 half-stages per block) = 48 / KS
+    constexpr int NPW = (NG + WAVES - 1) / WAVES;   // DMA pieces per wave per matrix
+    constexpr int DSTRIDE = (NM / 2) / (2 * NPW) > 0 ? (NM / 2) / (2 * NPW) : 1;   // DMA issue spread over the first half
+    // fragment addresses = per-lane pointer (swizzle resolved once per kernel) + compile-time immediate:
+    //   W1 k-step ks: w1p[ks % NA] + (ks / NA) * NA * 32;   W2 n-fragment nf, k-step kk: w2p[kk] + nf * 2048
+#define FFN_LD_W1(ks) (*(const bf16x8*)(w1p[(ks) % NA] + ring * CHB + ((ks) / NA) * NA * 32))
+#define FFN_LD_W2(f) (*(const bf16x8*)(w2p[(f) & 1] + ring * CHB + ((f) >> 1) * 2048))
+#define FFN_LD(f) (((f) & 1) ? FFN_LD_W2((f) >> 1) : FFN_LD_W1((f) >> 1))
+#define FFN_LD_ON(f) (((f) & 1) ? DO_C : DO_A)
+    bf16x8 wf[NF];
+    f32x4 bv[4];
+    GeluSt gs[NB][16];
+    float gout[NB][16];
+    if constexpr (DO_B) bv[0] = *(const f32x4*)(b1_prev + 4 * half);
+#pragma unroll
+    for (int f = 0; f < PF; ++f)
+        if (FFN_LD_ON(f)) wf[f] = FFN_LD(f);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int f = m / NB, nb = m % NB;
+        if ((f & 1) == 0) {
+            if constexpr (DO_A) {
+                const int ks = f >> 1;
+                if constexpr (VAR & 8) asm volatile("" ::"v"(wf[f]));      // ablation: no GEMM1 MFMA
+                else if (ks == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    s_out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f], afr[nb][ks], z, 0, 0, 0);
+                } else s_out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f], afr[nb][ks], s_out[nb], 0, 0, 0);
+            }
+        } else {
+            if constexpr (DO_C) {
+                const int g = f >> 1;
+                if constexpr (VAR & 4) asm volatile("" ::"v"(wf[f]), "v"(p_in[nb][g & 1]));   // ablation: no GEMM2 MFMA
+                else o[nb][g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f], p_in[nb][g & 1], o[nb][g >> 1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the MFMA opens the slot; everything below issues in its shadow
+        if (nb == 0 && f + PF < NF && FFN_LD_ON(f + PF)) wf[f + PF] = FFN_LD(f + PF);
+        if constexpr (DO_DMA) {             // next iteration's weight images, one 1-KiB piece per DSTRIDE slots
+            if (m % DSTRIDE == 0 && m / DSTRIDE < 2 * NPW) {
+                const int k = m / DSTRIDE, mat = k / NPW, piece = (k % NPW) * WAVES + uwave;
+                const int lane16 = (threadIdx.x & 63) * 16;
+                if (NG % WAVES == 0 || piece < NG) {
+                    if (mat == 0 && dma1) glds16(dma_src1 + piece * 1024 + lane16, dma_dst1 + piece * 1024);
+                    else if (mat == 1 && dma2) glds16(dma_src2 + piece * 1024 + lane16, dma_dst2 + piece * 1024);
+                }
+            }
+        }
+        if constexpr (DO_B) {               // GELU; value r of block gb <-> hidden h = (r&3) + 8(r>>2) + 4*half
+#pragma unroll
+            for (int q = 1; q < 4; ++q)     // bias of values 4q..4q+3 (first used by unit 24*q*NB): read ~2 slots ahead
+                if (m == ((24 * q * NB) / UPS >= 2 ? (24 * q * NB) / UPS - 2 : 0)) bv[q] = *(const f32x4*)(b1_prev + 8 * q + 4 * half);
+#pragma unroll
+            for (int u = m * UPS; u < (m + 1) * UPS; ++u) {     // unit u = (((pair j, half-stage h), block gb), member w)
+                const int w = u & 1, gb = (u >> 1) % NB, jh = (u >> 1) / NB, h = jh % 6, r = 2 * (jh / 6) + w;
+                if (VAR & 2) {               // ablation bit 1: no GELU math
+                    if (h == 5) gout[gb][r] = s_in[gb][r] + bv[r >> 2][r & 3];
+                } else {
+                    const float sv = s_in[gb][r], bb = bv[r >> 2][r & 3];
+                    if (h == 0) gelu_half<0>(gs[gb][r], sv, bb, gout[gb][r]);
+                    else if (h == 1) gelu_half<1>(gs[gb][r], sv, bb, gout[gb][r]);
+                    else if (h == 2) gelu_half<2>(gs[gb][r], sv, bb, gout[gb][r]);
+                    else if (h == 3) gelu_half<3>(gs[gb][r], sv, bb, gout[gb][r]);
+                    else if (h == 4) gelu_half<4>(gs[gb][r], sv, bb, gout[gb][r]);
+                    else gelu_half<5>(gs[gb][r], sv, bb, gout[gb][r]);
+                }
+                if (h == 5 && (r & 3) == 3) {
+                    const bf16x4 pk = f32_to_bf4(f32x4{gout[gb][r - 3], gout[gb][r - 2], gout[gb][r - 1], gout[gb][r]});
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p_out[gb][r >> 3][(r & 4) + j] = pk[j];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef FFN_LD_W1
+#undef FFN_LD_W2
+#undef FFN_LD
+#undef FFN_LD_ON
+}
+
+template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void ffn_fused_kernel(
+    const bf16* __restrict__ A, const char* __restrict__ w1img, const char* __restrict__ w2img,
+    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ ls,
     bf16* X, int M, int nwg)
 {
-    constexpr int HID = 4 * C;
-    constexpr int KS = C / 16;              // K=16 steps of GEMM1
-    constexpr int NFR = C / 32;             // 32-wide output fragments of GEMM2
-    constexpr int NSL = HID / HS;           // weight slices
-    constexpr int CH = HS / 32;             // 32-hidden-unit chunks per slice
-    constexpr int SPR1 = C / 8;             // 16-B slots per W1 row
-    constexpr int SPR2 = HS / 8;            // 16-B slots per W2 row
-    constexpr int SLICE_B = HS * C * 2;     // bytes of one W1 (or W2) slice
-    constexpr int NCHUNK = HS * C / 8 / 256;   // 16-B chunks per thread per matrix per slice
-    static_assert(HS * C / 8 % 256 == 0, "slice must split evenly over 256 threads");
+    constexpr int HID = 4 * C, KS = C / 16, NFR = C / 32, NCH = HID / 32;
+    constexpr int CHB = 64 * C;             // bytes of one W1 (or W2) chunk image
+    constexpr int NG = CHB / 1024;          // 1-KiB DMA pieces per chunk image
+    static_assert(NCH % 2 == 0, "pipeline is unrolled by two");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [buf0: W1 slice | W2 slice][buf1: ...][b1 fp32 HID]
-    float* lb1 = (float*)(smem + 4 * SLICE_B);
+    // [W1 ring: 2 x CHB][W2 ring: 2 x CHB][b1 fp32 HID]   - one array: see cdna_hip_programming.md 5 item 4(a)
+    char* w1ring = smem;
+    char* w2ring = smem + 2 * CHB;
+    float* lb1 = (float*)(smem + 4 * CHB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
     const int blk = xcd_remap(blockIdx.x, nwg);
-    const int m_row = blk * 128 + wave * 32 + li;
-    const int m_ld = min(m_row, M - 1);
+    const int row0 = blk * (32 * NB * WAVES) + wave * (32 * NB);
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);          // provably uniform: DMA bases stay in SGPRs / M0
+    const unsigned lds_w1 = __builtin_amdgcn_readfirstlane(lds_addr(w1ring)), lds_w2 = __builtin_amdgcn_readfirstlane(lds_addr(w2ring));
 
+#pragma unroll
+    for (int g = 0; g < (NG + WAVES - 1) / WAVES; ++g) {             // W1[0]
+        const int piece = g * WAVES + uwave;
+        if (NG % WAVES == 0 || piece < NG)
+            glds16(w1img + piece * 1024 + lane * 16, lds_w1 + piece * 1024);
+    }
+    for (int i = tid; i < HID / 4; i += WAVES * 64) *(f32x4*)&lb1[i * 4] = *(const f32x4*)&b1[i * 4];
+
+    // per-lane fragment pointers (ring slot 0), see ffn_iter
+    const char* w1p[C / 48];
+    const char* w2p[2];
+#pragma unroll
+    for (int k = 0; k < C / 48; ++k) w1p[k] = w1ring + w1_off<C>(li, 2 * k + half);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w2p[k] = w2ring + w2_off(li, 2 * k + half);
+
+    bf16x8 afr[NB][KS];
+    f32x16 o[NB][NFR];
+    f32x16 s0[NB], s1[NB];          // s[k&1] holds S(k)
+    bf16x8 p0[NB][2], p1[NB][2];    // p[k&1] holds P(k)
     // ---- A^T fragments (B operands), straight from global: lane reads 16 B of its own row per k-step
-    bf16x8 afr[KS];
-    {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int m_ld = min(row0 + nb * 32 + li, M - 1);
         const bf16* arow = A + (size_t)m_ld * C + half * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) afr[ks] = *(const bf16x8*)(arow + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) afr[nb][ks] = *(const bf16x8*)(arow + ks * 16);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int i = 0; i < NFR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nb][i][r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[nb][r] = 0.f; s1[nb][r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { p0[nb][0][r] = 0; p0[nb][1][r] = 0; p1[nb][0][r] = 0; p1[nb][1][r] = 0; }
     }
 
-    // ---- staging assignment ----
-    int s1_dst[NCHUNK], s2_dst[NCHUNK];
-    const bf16* s1_src[NCHUNK];
-    const bf16* s2_src[NCHUNK];
-#pragma unroll
-    for (int i = 0; i < NCHUNK; ++i) {
-        const int idx = i * 256 + tid;
-        const int r1 = idx / SPR1, c1 = idx % SPR1;
-        s1_src[i] = W1 + (size_t)r1 * C + c1 * 8;                 // + slice * HS * C
-        s1_dst[i] = w1_off<C>(r1, c1);
-        const int r2 = idx / SPR2, c2 = idx % SPR2;
-        s2_src[i] = W2s + (size_t)r2 * HS + c2 * 8;               // + slice * C * HS   (slice-major packing)
-        s2_dst[i] = SLICE_B + w2_off<HS>(r2, c2);
+    // Iteration t reads W1[t] (ring slot t&1) and W2[t-2] (ring slot t&1); it issues the DMA of W1[t+1] and W2[t-1] into the
+    // other slots, which every wave finished reading before this iteration's barrier.  FFN_SYNC = vmcnt(0) (the DMA is
+    // invisible to hipcc's own counting) + barrier: the images issued during the previous iteration have landed and are
+    // visible to every wave.  (w1img carries one zero chunk past the end, so W1[t+1] is always a valid source.)
+#define FFN_DMA_ARGS(t) w1img + (size_t)((t) < NCH ? (t) + 1 : 0) * CHB, lds_w1 + (((t) + 1) & 1) * CHB, (t) < NCH, \
+                        w2img + (size_t)((t) >= 1 ? (t) - 1 : 0) * CHB, lds_w2 + (((t) + 1) & 1) * CHB, (t) >= 1, uwave
+#define FFN_SYNC() ffn_wait_dma(); __syncthreads()
+    constexpr bool DMA = !(VAR & 1);        // ablation bit 0: no weight streaming in the steady state
+    FFN_SYNC();
+    ffn_iter<C, NB, WAVES, true, false, false, true, VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, half, FFN_DMA_ARGS(0));
+    FFN_SYNC();
+    ffn_iter<C, NB, WAVES, true, true, false, true, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1, half, FFN_DMA_ARGS(1));
+#pragma unroll 1
+    for (int t = 2; t < ((VAR & 16) ? 2 : NCH); t += 2) {   // ablation bit 4: no steady-state iterations (fixed per-workgroup cost only)
+        FFN_SYNC();                  // even t: S(t) -> s0, GELU(s1 + b1[t-1]) -> p1, GEMM2 reads p0
+        ffn_iter<C, NB, WAVES, true, true, true, DMA, VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1 + (t - 1) * 32, half, FFN_DMA_ARGS(t));
+        FFN_SYNC();                  // odd t:  S(t) -> s1, GELU(s0 + b1[t-1]) -> p0, GEMM2 reads p1
+        ffn_iter<C, NB, WAVES, true, true, true, DMA, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + t * 32, half, FFN_DMA_ARGS(t + 1));
     }
-    u32x4 r1v[NCHUNK], r2v[NCHUNK];
+    // the residual rows of X are fetched now (the A^T registers are dead from here on) so that their HBM latency hides
+    // behind the last two pipeline iterations instead of stalling the epilogue
+    bf16x4 xres[NB][NFR][4];
 #pragma unroll
-    for (int i = 0; i < NCHUNK; ++i) { r1v[i] = *(const u32x4*)s1_src[i]; r2v[i] = *(const u32x4*)s2_src[i]; }
-    for (int i = tid; i < HID / 4; i += 256) *(f32x4*)&lb1[i * 4] = *(const f32x4*)&b1[i * 4];
-#pragma unroll
-    for (int i = 0; i < NCHUNK; ++i) {
-        *(u32x4*)(smem + s1_dst[i]) = r1v[i];
-        *(u32x4*)(smem + s2_dst[i]) = r2v[i];
-    }
-    __syncthreads();
-
-    f32x16 o[NFR];
-#pragma unroll
-    for (int i = 0; i < NFR; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
-
-    for (int sl = 0; sl < NSL; ++sl) {
-        const char* buf = smem + (sl & 1) * 2 * SLICE_B;
-        if (sl + 1 < NSL) {
-            const size_t so = (size_t)(sl + 1) * HS * C;
-#pragma unroll
-            for (int i = 0; i < NCHUNK; ++i) { r1v[i] = *(const u32x4*)(s1_src[i] + so); r2v[i] = *(const u32x4*)(s2_src[i] + so); }
-        }
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            // GEMM1: S^T[32 hidden][32 rows]
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 wf = *(const bf16x8*)(buf + w1_off<C>(ch * 32 + li, ks * 2 + half));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, afr[ks], s, 0, 0, 0);
-            }
-            // bias + GELU; reg r <-> hidden h = (r&3) + 8(r>>2) + 4*half of this chunk
-            const float* bp = lb1 + sl * HS + ch * 32 + 4 * half;
-            f32x8 p0, p1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *(const f32x4*)(bp + 8 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float g = gelu_erf(s[4 * q + j] + bv[j]);
-                    if (q < 2) p0[4 * q + j] = g; else p1[4 * (q - 2) + j] = g;
-                }
-            }
-            const bf16x8 pf0 = f32_to_bf8(p0), pf1 = f32_to_bf8(p1);
-            // GEMM2: O^T[n][m] += W2chunk . P^T   (two K=16 steps)
-#pragma unroll
-            for (int nf = 0; nf < NFR; ++nf) {
-                const bf16x8 w0 = *(const bf16x8*)(buf + SLICE_B + w2_off<HS>(nf * 32 + li, ch * 4 + half));
-                const bf16x8 w1 = *(const bf16x8*)(buf + SLICE_B + w2_off<HS>(nf * 32 + li, ch * 4 + 2 + half));
-                o[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf0, o[nf], 0, 0, 0);
-                o[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf1, o[nf], 0, 0, 0);
-            }
-        }
-        if (sl + 1 < NSL) {
-            char* nb = smem + ((sl + 1) & 1) * 2 * SLICE_B;
-#pragma unroll
-            for (int i = 0; i < NCHUNK; ++i) {
-                *(u32x4*)(nb + s1_dst[i]) = r1v[i];
-                *(u32x4*)(nb + s2_dst[i]) = r2v[i];
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds out[m][n0 .. n0+3], n0 = nf*32 + 8q + 4*half -------------------------
-    if (m_row < M) {
-        bf16* xr = X + (size_t)m_row * C;
+    for (int nb = 0; nb < NB; ++nb) {
+        const bf16* xrd = X + (size_t)min(row0 + nb * 32 + li, M - 1) * C + 4 * half;
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n0 = nf * 32 + 8 * q + 4 * half;
-                const f32x4 bv = *(const f32x4*)(b2 + n0), lv = *(const f32x4*)(ls + n0);
-                const f32x4 rv = bf4_to_f32(*(const bf16x4*)(xr + n0));
-                f32x4 v;
+            for (int q = 0; q < 4; ++q) xres[nb][nf][q] = *(const bf16x4*)(xrd + nf * 32 + 8 * q);
+    }
+    FFN_SYNC();                      // t = NCH (even): GELU(S(NCH-1) in s1) -> p1, GEMM2(chunk NCH-2) reads p0; DMA W2[NCH-1]
+    ffn_iter<C, NB, WAVES, false, true, true, true, VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1 + (NCH - 1) * 32, half, FFN_DMA_ARGS(NCH));
+    FFN_SYNC();                      // t = NCH + 1: GEMM2(chunk NCH-1) reads p1
+    ffn_iter<C, NB, WAVES, false, false, true, false, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1, half, FFN_DMA_ARGS(NCH));
+#undef FFN_DMA_ARGS
+#undef FFN_SYNC
+
+    // ---- epilogue: lane holds out[m][n0 .. n0+3], n0 = nf*32 + 8q + 4*half -------------------------
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = rv[j] + lv[j] * (o[nf][4 * q + j] + bv[j]);
-                *(bf16x4*)(xr + n0) = f32_to_bf4(v);
-            }
+    for (int nb = 0; nb < NB; ++nb) {
+        const int m_row = row0 + nb * 32 + li;
+        if (m_row < M) {
+            bf16* xr = X + (size_t)m_row * C;
+#pragma unroll
+            for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = nf * 32 + 8 * q + 4 * half;
+                    const f32x4 bv = *(const f32x4*)(b2 + n0), lv = *(const f32x4*)(ls + n0);
+                    const f32x4 rv = bf4_to_f32(xres[nb][nf][q]);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = rv[j] + lv[j] * (o[nb][nf][4 * q + j] + bv[j]);
+                    *(bf16x4*)(xr + n0) = f32_to_bf4(v);
+                }
+        }
     }
 }
 
-template <int C, int HS, int OCC>
-static hipError_t launch_ffn(hipStream_t st, const bf16* A, const bf16* W1, const float* b1, const bf16* W2s,
+template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
+static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, const char* w2img, const float* b1,
                              const float* b2, const float* ls, bf16* X, int M)
 {
-    const int nwg = (M + 127) / 128;
-    const size_t shmem = (size_t)4 * HS * C * 2 + (size_t)4 * C * 4;
+    constexpr int ROWS = 32 * NB * WAVES;
+    const int nwg = (M + ROWS - 1) / ROWS;
+    const size_t shmem = (size_t)4 * 64 * C + (size_t)4 * C * 4 + 256;   // + pad: the last bias prefetch reads one chunk past b1
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<C, HS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ffn_fused_kernel<C, HS, OCC>), dim3(nwg), dim3(256), shmem, st, A, W1, b1, W2s, b2, ls, X, M, nwg);
+    hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
     return hipGetLastError();
 }
 
-// Hidden-slice size used for channel count C (also needed by the host packer for the W2 layout).
-extern "C" int fvhd_ffn_slice(int C) { return C == 384 ? 32 : C == 192 ? 32 : C == 96 ? 64 : 0; }
+// 1 if the fused kernel exists for this channel count
+extern "C" int fvhd_ffn_fused_supported(int C) { return C == 384 || C == 192 || C == 96; }
 
-// A [M,C] bf16; W1 bf16 [4C][C]; W2s bf16 slice-major [4C/HS][C][HS] with the hidden axis permuted inside every
-// 32-chunk (position 16kb+8half+j holds hidden 16kb+8(j>>2)+4half+(j&3)); b1 [4C], b2 [C], ls [C] fp32; X [M,C] in/out.
-extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* W1, const float* b1, const void* W2s,
+// Host-side packer: fc1 [4C][C] and fc2 [C][4C] (fp32, the reference's layouts) -> bf16 chunk images in LDS byte order.
+//   w1img: (4C/32 + 1) chunks of 64*C bytes (last chunk zero);  w2img: 4C/32 chunks of 64*C bytes.
+static uint16_t to_bf16(float f)      // round-to-nearest-even, as torch's .to(bfloat16)
+{
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uint16_t* w1img, uint16_t* w2img)
+{
+    if (!fvhd_ffn_fused_supported(C)) return 1;
+    const int HID = 4 * C, NCH = HID / 32, CHE = 32 * C;   // bf16 elements per chunk image
+    for (int i = 0; i < (NCH + 1) * CHE; ++i) w1img[i] = 0;
+    for (int ch = 0; ch < NCH; ++ch) {
+        uint16_t* i1 = w1img + (size_t)ch * CHE;
+        uint16_t* i2 = w2img + (size_t)ch * CHE;
+        for (int row = 0; row < 32; ++row)
+            for (int slot = 0; slot < C / 8; ++slot) {
+                const int off = (C == 384 ? w1_off<384>(row, slot) : C == 192 ? w1_off<192>(row, slot) : w1_off<96>(row, slot)) / 2;
+                for (int e = 0; e < 8; ++e) i1[off + e] = to_bf16(fc1[(size_t)(ch * 32 + row) * C + slot * 8 + e]);
+            }
+        for (int n = 0; n < C; ++n)
+            for (int slot = 0; slot < 4; ++slot) {
+                const int off = w2_off(n, slot) / 2;
+                for (int e = 0; e < 8; ++e) {
+                    const int pos = slot * 8 + e, kb = pos >> 4, hf = (pos >> 3) & 1, j = pos & 7;
+                    const int h = 16 * kb + 8 * (j >> 2) + 4 * hf + (j & 3);
+                    i2[off + e] = to_bf16(fc2[(size_t)n * HID + ch * 32 + h]);
+                }
+            }
+    }
+    return 0;
+}
+
+// A [M,C] bf16; w1img / w2img from fvhd_ffn_pack_host (device copies); b1 [4C], b2 [C], ls [C] fp32; X [M,C] in/out.
+extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* w1img, const float* b1, const void* w2img,
                                      const float* b2, const float* ls, void* X, int M, int C)
 {
     const bf16* a = (const bf16*)A;
-    const bf16* w1 = (const bf16*)W1;
-    const bf16* w2 = (const bf16*)W2s;
+    const char* w1 = (const char*)w1img;
+    const char* w2 = (const char*)w2img;
     bf16* x = (bf16*)X;
     hipError_t e = hipErrorInvalidValue;
     if (M <= 0) return (int)e;
-    if (C == 384) e = launch_ffn<384, 32, 1>(st, a, w1, b1, w2, b2, ls, x, M);
-    else if (C == 192) e = launch_ffn<192, 32, 2>(st, a, w1, b1, w2, b2, ls, x, M);
-    else if (C == 96) e = launch_ffn<96, 64, 2>(st, a, w1, b1, w2, b2, ls, x, M);
+    if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
+    else if (C == 192) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);   // 2 workgroups per CU
+    else if (C == 96) e = launch_ffn<96, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
+    return (int)e;
+}
+
+// Ablation variants for tools/bench_ops.py (NOT part of include/fvhd.h; results are wrong by construction when variant != 0):
+// bit0 no weight streaming, bit1 no GELU math, bit2 no GEMM2 MFMAs, bit3 no GEMM1 MFMAs; pf = LDS fragment prefetch depth.
+extern "C" int fvhd_debug_ffn_variant(hipStream_t st, const void* A, const void* w1img, const float* b1, const void* w2img,
+                                      const float* b2, const float* ls, void* X, int M, int C, int nb, int waves, int variant, int pf)
+{
+    const bf16* a = (const bf16*)A;
+    const char* w1 = (const char*)w1img;
+    const char* w2 = (const char*)w2img;
+    bf16* x = (bf16*)X;
+    hipError_t e = hipErrorInvalidValue;
+#define V(CC, NN, WW, VV, PP) if (C == CC && nb == NN && waves == WW && variant == VV && pf == PP) e = launch_ffn<CC, NN, WW, VV, PP>(st, a, w1, w2, b1, b2, ls, x, M);
+    V(384, 1, 4, 0, 3) V(384, 1, 4, 3, 3) V(384, 1, 4, 15, 3) V(384, 1, 4, 16, 3) V(192, 2, 4, 16, 3) V(192, 1, 8, 16, 3) V(96, 1, 8, 16, 3)
+    V(192, 1, 8, 0, 3) V(192, 2, 4, 0, 3) V(192, 2, 4, 0, 2) V(192, 2, 4, 3, 3) V(192, 2, 4, 1, 3) V(192, 2, 4, 2, 3) V(192, 2, 4, 12, 3)
+    V(96, 1, 8, 0, 3) V(96, 2, 4, 0, 3) V(96, 2, 4, 2, 3) V(96, 2, 4, 3, 3)
+    if (C == 192 && nb == 1 && waves == 4 && pf == 3) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);   // 2 workgroups / CU
+    if (C == 96 && nb == 1 && waves == 4 && pf == 3) e = launch_ffn<96, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
+    if (C == 96 && nb == 1 && waves == 4 && pf == 2) e = launch_ffn<96, 1, 4, 0, 2, 3>(st, a, w1, w2, b1, b2, ls, x, M);   // 3 workgroups / CU
+#undef V
     return (int)e;
 }

@@ -24,7 +24,8 @@ int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, 
                         void*, int, int, int, int, int);
 int fvhd_launch_cast_to_bf16(hipStream_t, const void*, int, void*, long);
 int fvhd_launch_ffn_fused(hipStream_t, const void*, const void*, const float*, const void*, const float*, const float*, void*, int, int);
-int fvhd_ffn_slice(int);
+int fvhd_ffn_fused_supported(int);
+int fvhd_ffn_pack_host(int, const float*, const float*, uint16_t*, uint16_t*);
 }
 
 namespace {
@@ -89,7 +90,7 @@ struct Packer {          // builds the packed weight image on the host; offsets 
 
 struct DwW { size_t w = 0, b = 0; int K = 0; };                    // taps fp32 [K*K][Cout], bias fp32 [Cout]
 struct GemmW { size_t w = 0, b = 0; int N = 0, K = 0; bool has_bias = false; };
-struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; size_t w2s = 0; bool fused = false; };   // w2s: fc2 weight in the fused kernel's layout
+struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; size_t w1img = 0, w2img = 0; bool fused = false; };   // w?img: chunk images of the fused kernel
 struct RepBlockW { DwW mixer; FfnW ffn; };
 struct AttnBlockW { size_t ln_w = 0, ln_b = 0, ls1 = 0; GemmW qkv, proj; FfnW ffn; };
 struct DownW { DwW dw; GemmW pw; };
@@ -135,6 +136,12 @@ struct fvhd_ctx {
     size_t ws_bytes = 0;
     int ws_batch = 0, ws_hidden = 0;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
+    // The batch is encoded as two independent halves on two HIP streams (FVHD_DUAL=0 disables): images are independent
+    // through the whole tower, and the MFMA-heavy ConvFFN kernels of one half co-run on the CUs with the VALU-bound
+    // depthwise kernels / HBM-bound prologues of the other.  aux joins back into the caller's stream before returning.
+    int dual = 1;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -223,22 +230,16 @@ bool pack_ffn(fvhd_ctx* c, Packer& pk, const std::string& p, const std::string& 
     if (!pack_dw(c, pk, p + ".convffn.conv.conv.weight", "", C, 7, &out->dw7, &s, &b)) return false;
     if (!pack_gemm(c, pk, p + ".convffn.fc1.weight", p + ".convffn.fc1.bias", 4 * C, C, true, &out->fc1)) return false;
     if (!pack_gemm(c, pk, p + ".convffn.fc2.weight", p + ".convffn.fc2.bias", C, 4 * C, true, &out->fc2)) return false;
-    // fc2 weight for the fused MLP kernel (ffn_fused.hip): slice-major [4C/HS][C][HS], hidden axis permuted inside
-    // every 32-chunk so that position 16kb + 8half + j holds hidden unit 16kb + 8(j>>2) + 4half + (j&3).
-    const int HS = fvhd_ffn_slice(C);
-    if (HS > 0) {
+    // chunk images for the fused MLP kernel (ffn_fused.hip: fvhd_ffn_pack_host)
+    if (fvhd_ffn_fused_supported(C)) {
+        const HostTensor* w1 = find(c, p + ".convffn.fc1.weight", {4 * C, C, 1, 1});
         const HostTensor* w2 = find(c, p + ".convffn.fc2.weight", {C, 4 * C, 1, 1});
-        if (!w2) return false;
-        const int HID = 4 * C, NSL = HID / HS;
-        std::vector<float> t((size_t)C * HID);
-        for (int sl = 0; sl < NSL; ++sl)
-            for (int n = 0; n < C; ++n)
-                for (int pos = 0; pos < HS; ++pos) {
-                    const int ch = pos >> 5, q = pos & 31, kb = q >> 4, hf = (q >> 3) & 1, j = q & 7;
-                    const int h = 16 * kb + 8 * (j >> 2) + 4 * hf + (j & 3);
-                    t[((size_t)sl * C + n) * HS + pos] = w2->data[(size_t)n * HID + sl * HS + ch * 32 + h];
-                }
-        out->w2s = pk.add_bf16(t.data(), t.size());
+        if (!w1 || !w2) return false;
+        const size_t che = (size_t)32 * C, nch = (size_t)4 * C / 32;
+        out->w1img = pk.reserve((nch + 1) * che * 2);
+        out->w2img = pk.reserve(nch * che * 2);     // (reserve may move buf: take the pointers after both calls)
+        if (fvhd_ffn_pack_host(C, w1->data.data(), w2->data.data(), (uint16_t*)(pk.buf.data() + out->w1img),
+                               (uint16_t*)(pk.buf.data() + out->w2img))) return false;
         out->fused = true;
     }
     return pack_vec(c, pk, ls_key, {C, 1, 1}, &out->ls);
@@ -343,7 +344,7 @@ int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, in
     if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0))) return e;
     if (f.fused && c->use_fused_ffn) {
         Scope s(c, st, C_FFN);
-        CHECK_LAUNCH(fvhd_launch_ffn_fused(st, w.A, c->wdev + f.fc1.w, c->wp<float>(f.fc1.b), c->wdev + f.w2s,
+        CHECK_LAUNCH(fvhd_launch_ffn_fused(st, w.A, c->wdev + f.w1img, c->wp<float>(f.fc1.b), c->wdev + f.w2img,
                                            c->wp<float>(f.fc2.b), c->wp<float>(f.ls), x, M, C),
                      "fused ffn launch");
         return 0;
@@ -423,15 +424,57 @@ int prepare(fvhd_ctx* c, int B)
     return ensure_ws(c, B);
 }
 
+// the part of workspace `w` (carved for `total` images) that belongs to the images [b0, total)
+Ws sub_ws(const fvhd_ctx* c, const Ws& w, int b0)
+{
+    const size_t unit1 = (size_t)(c->R / 4) * (c->R / 4) * 96 * 2;     // per-image bytes of X / T / A (H: 4x)
+    Ws h = w;
+    h.X += unit1 * b0; h.T += unit1 * b0; h.A += unit1 * b0; h.H += 4 * unit1 * b0;
+    h.pooled += (size_t)b0 * (kOutDim + kSeRd);
+    h.scale += (size_t)b0 * kOutDim;
+    return h;
+}
+
+size_t dtype_size(int dt) { return dt == FVHD_F32 ? 4 : 2; }
+
 int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out, int out_dtype, hipStream_t st)
 {
     if (img_dtype < 0 || img_dtype > 2 || out_dtype < 0 || out_dtype > 2) return fail("fvhd_encode: bad dtype");
     int e = prepare(c, B);
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
-    char *X = w.X, *T = w.T;
-    for (const Step& sp : c->m.steps)
-        if ((e = run_step(c, st, sp, w, X, T, B, images, img_dtype, out, out_dtype))) return e;
+    if (!c->dual || B < 2) {
+        char *X = w.X, *T = w.T;
+        for (const Step& sp : c->m.steps)
+            if ((e = run_step(c, st, sp, w, X, T, B, images, img_dtype, out, out_dtype))) return e;
+        return 0;
+    }
+    // ---- two halves on two streams ----
+    if (!c->aux) {
+        hipError_t he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (he != hipSuccess) return hip_fail("aux stream/event creation", he);
+    }
+    const int B0 = B / 2, B1 = B - B0;
+    const size_t Tn = (size_t)(c->R / 64) * (c->R / 64);
+    const Ws w1 = sub_ws(c, w, B0);
+    const void* img1 = (const char*)images + (size_t)B0 * 3 * c->R * c->R * dtype_size(img_dtype);
+    void* out1 = (char*)out + (size_t)B0 * Tn * kOutDim * dtype_size(out_dtype);
+    hipError_t he = hipEventRecord(c->ev_fork, st);
+    if (he == hipSuccess) he = hipStreamWaitEvent(c->aux, c->ev_fork, 0);
+    if (he != hipSuccess) return hip_fail("fork", he);
+    char *X0 = w.X, *T0 = w.T, *X1 = w1.X, *T1 = w1.T;
+    const int n = (int)c->m.steps.size();
+    const int skew = c->dual >= 2 ? c->dual - 1 : 0;     // FVHD_DUAL=k+1: the second half is issued k steps behind the first
+    for (int i = 0; i < n + skew; ++i) {
+        if (i < n && (e = run_step(c, st, c->m.steps[i], w, X0, T0, B0, images, img_dtype, out, out_dtype))) return e;
+        const int j = i - skew;
+        if (j >= 0 && (e = run_step(c, c->aux, c->m.steps[j], w1, X1, T1, B1, img1, img_dtype, out1, out_dtype))) return e;
+    }
+    he = hipEventRecord(c->ev_join, c->aux);
+    if (he == hipSuccess) he = hipStreamWaitEvent(st, c->ev_join, 0);
+    if (he != hipSuccess) return hip_fail("join", he);
     return 0;
 }
 
@@ -475,6 +518,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->R = image_size;
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_DUAL")) c->dual = atoi(ev);
     *out = c;
     return 0;
 }
@@ -486,6 +530,9 @@ void fvhd_destroy(fvhd_ctx* c)
     (void)hipDeviceSynchronize();
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& ev : c->ev_pool) (void)hipEventDestroy(ev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->pdev) (void)hipFree(c->pdev);
     if (c->ws) (void)hipFree(c->ws);
@@ -768,11 +815,19 @@ int fvhd_op_se_head(fvhd_stream_t st, const void* y, float* pooled, float* scale
     return e ? hip_fail("fvhd_op_se_head", (hipError_t)e) : 0;
 }
 
-int fvhd_op_ffn_fused(fvhd_stream_t st, const void* A, const void* W1, const float* b1, const void* W2s, const float* b2,
+int fvhd_op_ffn_fused(fvhd_stream_t st, const void* A, const void* w1img, const float* b1, const void* w2img, const float* b2,
                       const float* ls, void* X, int M, int C)
 {
-    int e = fvhd_launch_ffn_fused((hipStream_t)st, A, W1, b1, W2s, b2, ls, X, M, C);
+    int e = fvhd_launch_ffn_fused((hipStream_t)st, A, w1img, b1, w2img, b2, ls, X, M, C);
     return e ? hip_fail("fvhd_op_ffn_fused", (hipError_t)e) : 0;
+}
+
+int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img)
+{
+    if (!host_fc1 || !host_fc2 || !host_w1img || !host_w2img) return fail("fvhd_ffn_pack: NULL argument");
+    if (fvhd_ffn_pack_host(C, host_fc1, host_fc2, (uint16_t*)host_w1img, (uint16_t*)host_w2img))
+        return fail("fvhd_ffn_pack: the fused ConvFFN kernel exists for C in {96, 192, 384}");
+    return 0;
 }
 
 }  // extern "C"

@@ -57,3 +57,44 @@ def test_no_cpu_fallback(lib):
     assert lib.fvhd_create(ctypes.byref(h), 0, 1024, 1) != 0
     assert b"no HIP device" in lib.fvhd_last_error()
     assert not h.value
+
+
+@pytest.mark.parametrize("C", [96, 192, 384])
+def test_ffn_pack_layout(lib, C):
+    """fvhd_ffn_pack (host-only): the chunk images are the documented XOR-swizzled LDS byte order, restated here
+    independently of the C++ packer."""
+    HID, nch, che = 4 * C, 4 * C // 32, 32 * C
+    g = torch.Generator().manual_seed(C)
+    w1 = torch.randn(HID, C, generator=g).to(torch.bfloat16).float().contiguous()
+    w2 = torch.randn(C, HID, generator=g).to(torch.bfloat16).float().contiguous()
+    i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
+    i2 = torch.empty(nch * che, dtype=torch.bfloat16)
+    vp = ctypes.c_void_p
+    assert lib.fvhd_ffn_pack(C, vp(w1.data_ptr()), vp(w2.data_ptr()), vp(i1.data_ptr()), vp(i2.data_ptr())) == 0
+    assert lib.fvhd_ffn_pack(128, vp(w1.data_ptr()), vp(w2.data_ptr()), vp(i1.data_ptr()), vp(i2.data_ptr())) != 0
+    i1, i2 = i1.float(), i2.float()
+    assert torch.count_nonzero(i1[nch * che:]) == 0
+
+    def w1_off(row, slot):      # bytes
+        if C == 384:
+            return row * 768 + ((slot ^ (row & 15)) << 4)
+        if C == 192:
+            return row * 384 + ((slot ^ ((row >> 1) & 7)) << 4)
+        return row * 192 + ((slot ^ ((row >> 2) & 3)) << 4)
+
+    def w2_off(row, slot):
+        return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4)
+
+    for ch in (0, 1, nch - 1):
+        for row in (0, 5, 17, 31):
+            for slot in (0, 3, C // 8 - 1):
+                o = ch * che + w1_off(row, slot) // 2
+                assert torch.equal(i1[o:o + 8], w1[ch * 32 + row, slot * 8: slot * 8 + 8])
+        for n in (0, 7, C - 1):
+            for slot in range(4):
+                o = ch * che + w2_off(n, slot) // 2
+                for e in range(8):
+                    pos = slot * 8 + e
+                    kb, hf, j = pos >> 4, (pos >> 3) & 1, pos & 7
+                    h = 16 * kb + 8 * (j >> 2) + 4 * hf + (j & 3)
+                    assert i2[o + e] == w2[n, ch * 32 + h]

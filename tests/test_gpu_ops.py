@@ -118,26 +118,32 @@ def test_gemm_rejects_bad_shapes():
 
 
 # ------------------------------------------------------------------------------------------- fused FFN
-def _pack_w2(W2, HS):
-    """fc2 weight [C, 4C] -> slice-major [4C/HS, C, HS] with the documented in-chunk hidden permutation."""
-    Cc, HID = W2.shape
-    pos = torch.arange(HS)
-    ch, q = pos >> 5, pos & 31
-    kb, hf, j = q >> 4, (q >> 3) & 1, q & 7
-    src = ch * 32 + 16 * kb + 8 * (j >> 2) + 4 * hf + (j & 3)
-    return W2.reshape(Cc, HID // HS, HS)[:, :, src].permute(1, 0, 2).contiguous()
+def _pack_ffn(W1, W2):
+    """fc1 [4C,C], fc2 [C,4C] (fp32 values already bf16-representable) -> device chunk images via fvhd_ffn_pack."""
+    lib = _lib.load()
+    HID, Cc = W1.shape
+    nch, che = HID // 32, 32 * Cc
+    i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
+    i2 = torch.empty(nch * che, dtype=torch.bfloat16)
+    w1, w2 = W1.float().contiguous(), W2.float().contiguous()
+    _lib.check(lib.fvhd_ffn_pack(Cc, _p(w1), _p(w2), _p(i1), _p(i2)), "fvhd_ffn_pack")
+    assert torch.equal(i1[nch * che:].float(), torch.zeros(che)), "zero chunk past the end of w1img"
+    # the images are permutations of the weights: same multiset of values
+    assert torch.equal(i1[: nch * che].float().sort().values, w1.flatten().sort().values)
+    assert torch.equal(i2.float().sort().values, w2.flatten().sort().values)
+    return i1.to(DEV), i2.to(DEV)
 
 
-@pytest.mark.parametrize("C,M", [(96, 300), (192, 256), (384, 131), (384, 1024), (96, 1)])
+@pytest.mark.parametrize("C,M", [(96, 300), (192, 256), (384, 131), (384, 1024), (96, 1), (192, 2049), (96, 5000)])
 def test_ffn_fused(C, M):
     lib = _lib.load()
     HID = 4 * C
-    HS = lib.fvhd_ffn_slice(C)
-    assert HS in (32, 64)
+    assert lib.fvhd_ffn_fused_supported(C) == 1 and lib.fvhd_ffn_fused_supported(768) == 0
     A, X = _bf(_rand(M, C, seed=1)), _bf(_rand(M, C, seed=2))
     W1, W2 = _bf(_rand(HID, C, seed=3, scale=C ** -0.5)), _bf(_rand(C, HID, seed=4, scale=HID ** -0.5))
     b1, b2, ls = _rand(HID, seed=5, scale=0.2), _rand(C, seed=6, scale=0.2), torch.rand(C, generator=torch.Generator().manual_seed(7))
-    ad, xd, w1d, w2d = A.to(DEV), X.to(DEV), W1.to(DEV), _pack_w2(W2, HS).to(DEV)
+    w1d, w2d = _pack_ffn(W1, W2)
+    ad, xd = A.to(DEV), X.to(DEV)
     b1d, b2d, lsd = b1.to(DEV), b2.to(DEV), ls.to(DEV)
     _lib.check(lib.fvhd_op_ffn_fused(_stream(), _p(ad), _p(w1d), _p(b1d), _p(w2d), _p(b2d), _p(lsd), _p(xd), M, C), "ffn_fused")
     torch.cuda.synchronize()
@@ -146,17 +152,39 @@ def test_ffn_fused(C, M):
     _close(xd, want, what=f"ffn_fused C{C} M{M}")
 
 
+def test_ffn_fused_hidden_order_is_asymmetric_safe():
+    """One-hot probes: W1 = selector of a single input channel per hidden unit, W2 = selector of a single hidden
+    unit per output channel, distinct biases - any mix-up of the hidden permutation or of rows/columns shows."""
+    lib = _lib.load()
+    C, M = 96, 64
+    HID = 4 * C
+    g = torch.Generator().manual_seed(11)
+    A, X = _bf(_rand(M, C, seed=1)), torch.zeros(M, C)
+    src = torch.randint(0, C, (HID,), generator=g)                      # hidden h copies input channel src[h]
+    W1 = torch.zeros(HID, C); W1[torch.arange(HID), src] = 1.0
+    pick = torch.randperm(HID, generator=g)[:C]                         # output n reads hidden pick[n]
+    W2 = torch.zeros(C, HID); W2[torch.arange(C), pick] = 1.0
+    b1, b2, ls = torch.linspace(-1, 1, HID), torch.zeros(C), torch.ones(C)
+    w1d, w2d = _pack_ffn(W1, W2)
+    xd, ad, b1d, b2d, lsd = X.to(DEV, torch.bfloat16), A.to(DEV), b1.to(DEV), b2.to(DEV), ls.to(DEV)   # keep alive
+    _lib.check(lib.fvhd_op_ffn_fused(_stream(), _p(ad), _p(w1d), _p(b1d), _p(w2d), _p(b2d), _p(lsd), _p(xd), M, C), "ffn_fused")
+    torch.cuda.synchronize()
+    want = _bf(O.gelu(A.float()[:, src[pick]] + b1[pick]))
+    _close(xd, want.float(), rtol=1e-2, atol_rms=2e-3, what="ffn one-hot probe")
+
+
 def test_ffn_fused_matches_two_gemm_route():
     """Same math as fc1(+GELU) -> fc2(+ls,+resid) through the plain GEMM kernel."""
     lib = _lib.load()
     C, M = 192, 640
-    HID, HS = 4 * C, lib.fvhd_ffn_slice(192)
+    HID = 4 * C
     A, X = _rand(M, C, seed=1), _rand(M, C, seed=2)
     W1, W2 = _rand(HID, C, seed=3, scale=C ** -0.5), _rand(C, HID, seed=4, scale=HID ** -0.5)
     b1, b2, ls = _rand(HID, seed=5, scale=0.2), _rand(C, seed=6, scale=0.2), torch.full((C,), 0.3)
     hid = _gemm(A, W1, b1, None, None, _lib.EPI_BIAS_GELU)
     two = _gemm(hid.float().cpu(), W2, b2, ls, X, _lib.EPI_BIAS_LS_RESID)
-    ad, xd, w1d, w2d = _bf(A).to(DEV), _bf(X).to(DEV), _bf(W1).to(DEV), _pack_w2(_bf(W2), HS).to(DEV)
+    w1d, w2d = _pack_ffn(_bf(W1), _bf(W2))
+    ad, xd = _bf(A).to(DEV), _bf(X).to(DEV)
     b1d, b2d, lsd = b1.to(DEV), b2.to(DEV), ls.to(DEV)
     _lib.check(lib.fvhd_op_ffn_fused(_stream(), _p(ad), _p(w1d), _p(b1d), _p(w2d), _p(b2d), _p(lsd), _p(xd), M, C), "ffn_fused")
     torch.cuda.synchronize()
@@ -178,6 +206,11 @@ def _pack_dw(w):   # [Cout,1,K,K] -> fp32 [K*K][Cout]
     (7, 2, 2, 1, 96, 16, 12),      # PatchEmbed 96 -> 192
     (7, 2, 2, 1, 768, 6, 6),       # PatchEmbed 768 -> 1536
     (3, 1, 2, 0, 1536, 4, 4),      # conv_exp
+    (7, 1, 1, 0, 192, 40, 37),     # several tiles in x and y, ragged right / bottom edges
+    (3, 1, 1, 0, 384, 33, 20),
+    (7, 2, 2, 1, 192, 40, 25),     # stride 2, odd width
+    (3, 2, 1, 1, 96, 70, 66),      # stem[1]: 3 tiles in y
+    (3, 1, 2, 0, 64, 20, 20),
 ])
 def test_dwconv(K, S, mult, gelu, Cin, H, W):
     lib = _lib.load()
@@ -195,6 +228,13 @@ def test_dwconv(K, S, mult, gelu, Cin, H, W):
     if gelu:
         want = O.gelu(want)
     _close(y.permute(0, 3, 1, 2), want, what=f"dwconv K{K} S{S} m{mult}")
+
+
+def test_dwconv_unsupported_channel_count_is_an_error():
+    lib = _lib.load()
+    x = torch.zeros(1, 9, 9, 48, dtype=torch.bfloat16, device=DEV)       # 48 output channels: neither 64- nor 96-divisible
+    w = torch.zeros(49, 48, device=DEV)
+    assert lib.fvhd_op_dwconv(_stream(), _p(x), _p(x), _p(w), None, 1, 9, 9, 48, 7, 1, 1, 0) != 0
 
 
 def test_dwconv_no_bias():

@@ -34,13 +34,17 @@ def _nhwc_bf16(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
 
 
-def _run_teacher_forced(res, batch, sd, seed):
+def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16):
     tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{res}", SimpleNamespace(unfreeze_mm_vision_tower=False))
     tower.vision_tower.model.load_state_dict(sd, strict=True)
-    tower = tower.to(DEV, torch.bfloat16)
+    tower = tower.to(DEV, param_dtype)             # as model/builder.py:173 does: the PARAMETERS are cast too
     ctx = tower._context()
     info = ctx.steps()
-    fns = E.step_fns(sd)
+    # the emulation must see the weights the tower holds: bf16-rounded values when the module was cast to bf16
+    # (GEMM weights are rounded to bf16 by the library in either case; depthwise taps, biases, norms and layer
+    # scales are used in fp32 as given)
+    held = {k: (v.to(param_dtype).float() if v.is_floating_point() else v) for k, v in sd.items()}
+    fns = E.step_fns(held)
     assert len(info) == len(fns) == 52
     x = synth.synthetic_images(batch, res, seed=seed).to(torch.bfloat16).float()
     worst = (0.0, "")
@@ -78,6 +82,10 @@ def _run_teacher_forced(res, batch, sd, seed):
 def test_steps_teacher_forced_r256(synth_sd):
     worst = _run_teacher_forced(256, 2, synth_sd, seed=3)
     print("worst step:", worst)
+
+
+def test_steps_teacher_forced_r256_fp32_parameters(synth_sd):
+    _run_teacher_forced(256, 1, synth_sd, seed=6, param_dtype=torch.float32)
 
 
 def test_steps_teacher_forced_r320_ragged(synth_sd):

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Per-op microbenchmarks through the C ABI at the BASELINE.json config-2 shapes (B=32, 1024x1024):
+HIP-event timing on the launch stream, algorithmic FLOP/s and bytes/s.  GPU only.
+    python tools/bench_ops.py [ffn] [dw] [gemm] [attn] [stem]
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ml_fastvlm_amd import _lib  # noqa: E402
+
+DEV = "cuda:0"
+lib = _lib.load()
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
+
+
+def timeit(fn, iters=20, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def bench_ffn(B=32, variants=True):
+    for Cc, H in ((96, 256), (192, 128), (384, 64)):
+        M, HID = B * H * H, 4 * Cc
+        g = torch.Generator().manual_seed(0)
+        A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+        X = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+        W1 = (torch.randn(HID, Cc, generator=g) * Cc ** -0.5).to(torch.bfloat16).float().contiguous()
+        W2 = (torch.randn(Cc, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).float().contiguous()
+        nch, che = HID // 32, 32 * Cc
+        i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
+        i2 = torch.empty(nch * che, dtype=torch.bfloat16)
+        _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
+        i1, i2 = i1.to(DEV), i2.to(DEV)
+        b1 = torch.randn(HID, generator=g).to(DEV) * 0.1
+        b2 = torch.randn(Cc, generator=g).to(DEV) * 0.1
+        ls = torch.full((Cc,), 0.01, device=DEV)
+        t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
+        fl, by = 16.0 * M * Cc * Cc, 6.0 * M * Cc
+        print(f"ffn_fused C={Cc:4d} M={M:8d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.1f} GB/s (algorithmic)")
+        if variants:
+            raw = C.CDLL(_lib.LIB_PATH)
+            f = raw.fvhd_debug_ffn_variant
+            f.argtypes = [C.c_void_p] * 8 + [C.c_int] * 6
+            names = {0: "full", 1: "no weight DMA", 2: "no GELU", 3: "no DMA, no GELU", 12: "no MFMA", 13: "no MFMA, no DMA", 15: "LDS reads + barriers only", 16: "prologue + 4 edge iterations + epilogue only"}
+            combos = {384: [(1, 4, 0, 3), (1, 4, 3, 3), (1, 4, 15, 3), (1, 4, 16, 3)],
+                      192: [(1, 8, 0, 3), (2, 4, 0, 3), (2, 4, 0, 2), (2, 4, 3, 3), (2, 4, 1, 3), (1, 4, 0, 3), (2, 4, 16, 3), (1, 8, 16, 3)],
+                      96: [(1, 8, 0, 3), (2, 4, 0, 3), (1, 4, 0, 3), (1, 4, 0, 2), (1, 8, 16, 3)]}[Cc]
+            for nb, wv, v, pf in combos:
+                tv = timeit(lambda: f(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc, nb, wv, v, pf))
+                print(f"    NB={nb} waves={wv} variant {v:2d} pf={pf} ({names[v]:26s}): {tv*1e6:9.1f} us  {fl/tv/1e12:7.1f} TF/s")
+
+
+def bench_dw(B=32):
+    for K, S, mult, gelu, Cc, H in ((3, 1, 1, 0, 96, 256), (3, 1, 1, 0, 192, 128), (3, 1, 1, 0, 384, 64),
+                                    (7, 1, 1, 0, 96, 256), (7, 1, 1, 0, 192, 128), (7, 1, 1, 0, 384, 64),
+                                    (7, 1, 1, 0, 768, 32), (7, 1, 1, 0, 1536, 16),
+                                    (7, 2, 2, 1, 96, 256), (7, 2, 2, 1, 192, 128), (7, 2, 2, 1, 384, 64), (7, 2, 2, 1, 768, 32),
+                                    (3, 2, 1, 1, 96, 512)):
+        OH = H // S
+        x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+        y = torch.empty(B, OH, OH, Cc * mult, device=DEV, dtype=torch.bfloat16)
+        w = torch.randn(K * K, Cc * mult, device=DEV)
+        bias = torch.randn(Cc * mult, device=DEV)
+        t = timeit(lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, K, S, mult, gelu)))
+        by = 2.0 * (x.numel() + y.numel())
+        fl = 2.0 * y.numel() * K * K
+        print(f"dwconv K={K} S={S} mult={mult} C={Cc:4d} H={H:3d}: {t*1e6:9.1f} us  {by/t/1e9:7.1f} GB/s  {fl/t/1e12:6.2f} TF/s")
+
+
+def bench_gemm(B=32):
+    shapes = [("stem 1x1", B * 65536, 96, 96, 2), ("down0 1x1", B * 16384, 192, 192, 2), ("down1 1x1", B * 4096, 384, 384, 2),
+              ("down2 1x1", B * 1024, 768, 768, 2), ("down3 1x1", B * 256, 1536, 1536, 2),
+              ("s3 qkv", B * 1024, 2304, 768, 0), ("s3 proj", B * 1024, 768, 768, 3), ("s3 fc1", B * 1024, 3072, 768, 2),
+              ("s3 fc2", B * 1024, 768, 3072, 3), ("s4 qkv", B * 256, 4608, 1536, 0), ("s4 proj", B * 256, 1536, 1536, 3),
+              ("s4 fc1", B * 256, 6144, 1536, 2), ("s4 fc2", B * 256, 1536, 6144, 3),
+              ("proj0 H896", B * 256, 896, 3072, 2), ("proj2 H896", B * 256, 896, 896, 1),
+              ("proj0 H3584", B * 256, 3584, 3072, 2), ("proj2 H3584", B * 256, 3584, 3584, 1)]
+    for name, M, N, K, epi in shapes:
+        A = torch.randn(M, K).to(DEV, torch.bfloat16)
+        W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
+        bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
+        out = torch.randn(M, N).to(DEV, torch.bfloat16)
+        t = timeit(lambda: _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(out), p(out), M, N, K, epi, 2)))
+        print(f"gemm {name:12s} M={M:8d} N={N:5d} K={K:5d} epi={epi}: {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+
+
+def bench_attn(B=32):
+    for N, Cc in ((1024, 768), (256, 1536), (2304, 768), (576, 1536)):
+        qkv = torch.randn(B * N, 3 * Cc).to(DEV, torch.bfloat16)
+        out = torch.empty(B * N, Cc, device=DEV, dtype=torch.bfloat16)
+        t = timeit(lambda: _lib.check(lib.fvhd_op_attention(stream(), p(qkv), p(out), B, N, Cc)))
+        fl = 4.0 * B * (Cc // 32) * N * N * 32
+        print(f"attention N={N:5d} C={Cc:5d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
+    for w in which:
+        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "gemm": bench_gemm, "attn": bench_attn}[w]()

@@ -22,9 +22,10 @@ def main(path):
     for n, c, s, a, mn, mx in rows:
         n = n if len(n) < 110 else n[:107] + "..."
         print(f"| `{n}` | {c} | {s/1e3:.1f} | {a/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {100*s/total:.2f} |")
-    try:
-        pm = cur.execute("select k.name, p.counter_name, count(*), sum(p.value) from pmc_events p join kernels k on "
-                         "p.dispatch_id = k.dispatch_id group by 1,2 order by 1,2").fetchall()
+    try:   # one row per (dispatch, counter, dimension instance): sum the instances, then aggregate over dispatches
+        pm = cur.execute("select name, counter_name, count(*), sum(v) from (select name, counter_name, dispatch_id, "
+                         "sum(counter_value) as v from pmc_events group by name, counter_name, dispatch_id) "
+                         "group by 1,2 order by 1,2").fetchall()
     except sqlite3.Error:
         pm = []
     if pm:
