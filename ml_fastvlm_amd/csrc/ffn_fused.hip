@@ -303,18 +303,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     }
 }
 
+static int g_ffn_lds_pad = 0;     // debug: extra dynamic LDS per workgroup (occupancy experiments, tools/bench_ops.py)
+extern "C" void fvhd_debug_set_ffn_lds_pad(int bytes) { g_ffn_lds_pad = bytes; }
+
 template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
 static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, const char* w2img, const float* b1,
                              const float* b2, const float* ls, bf16* X, int M)
 {
     constexpr int ROWS = 32 * NB * WAVES;
     const int nwg = (M + ROWS - 1) / ROWS;
-    const size_t shmem = (size_t)4 * 64 * C + (size_t)4 * C * 4 + 256;   // + pad: the last bias prefetch reads one chunk past b1
-    static bool attr_set = false;
-    if (!attr_set) {
+    const size_t shmem = (size_t)4 * 64 * C + (size_t)4 * C * 4 + 256 + g_ffn_lds_pad;   // + pad: the last bias prefetch reads one chunk past b1
+    static int attr_set = -1;
+    if (attr_set != g_ffn_lds_pad) {
         hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = g_ffn_lds_pad;
     }
     hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
     return hipGetLastError();

@@ -443,7 +443,7 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
     int e = prepare(c, B);
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
-    if (!c->dual || B < 2) {
+    if (!c->dual || B < 2 || c->prof) {   // profiling brackets single launches with events: keep them on one stream, un-overlapped
         char *X = w.X, *T = w.T;
         for (const Step& sp : c->m.steps)
             if ((e = run_step(c, st, sp, w, X, T, B, images, img_dtype, out, out_dtype))) return e;

@@ -1,0 +1,10 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench.json'))
+print(d['value'], d['ms_per_step'], d['roofline'])
+for k,v in d['kernels'].items(): print(k, v)
+PY

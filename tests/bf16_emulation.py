@@ -56,7 +56,8 @@ def step_fns(p):
     steps = []
 
     def stem(x):
-        x = rb(O.gelu(F.conv2d(x, p["patch_embed.0.reparam_conv.weight"], p["patch_embed.0.reparam_conv.bias"], stride=2, padding=1)))
+        # stem[0] is an MFMA GEMM in the HIP path: image and taps rounded to bf16
+        x = rb(O.gelu(F.conv2d(rb(x), rb(p["patch_embed.0.reparam_conv.weight"]), p["patch_embed.0.reparam_conv.bias"], stride=2, padding=1)))
         x = rb(O.gelu(F.conv2d(x, p["patch_embed.1.reparam_conv.weight"], p["patch_embed.1.reparam_conv.bias"], stride=2, padding=1, groups=96)))
         return rb(O.gelu(F.conv2d(x, rb(p["patch_embed.2.reparam_conv.weight"]), p["patch_embed.2.reparam_conv.bias"])))
 

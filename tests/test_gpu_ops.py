@@ -313,8 +313,29 @@ def test_stem_conv(dtype):
     imd, bd = img.to(DEV), b.to(DEV)
     _lib.check(lib.fvhd_op_stem_conv(_stream(), _p(imd), _lib.dtype_code(dtype), _p(out), _p(wd), _p(bd), B, R), "stem")
     torch.cuda.synchronize()
-    want = O.gelu(F.conv2d(img.float(), w, b, stride=2, padding=1))
+    # the kernel is an MFMA GEMM: image and taps are rounded to bf16 (the tower's compute dtype), accumulation is fp32
+    want = O.gelu(F.conv2d(_bf(img).float(), _bf(w).float(), b, stride=2, padding=1))
     _close(out.permute(0, 3, 1, 2), want, what=f"stem conv {dtype}")
+
+
+def test_stem_conv_tap_order():
+    """One-hot taps: output channel c copies exactly input tap (ci, ky, kx) = c-th of the 27 - any mix-up of the k-slot
+    order of the im2col gather against the weight fragment image shows as a wrong pixel."""
+    lib = _lib.load()
+    B, R = 1, 64
+    img = torch.rand(B, 3, R, R, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
+    w = torch.zeros(96, 3, 3, 3)
+    for c in range(96):
+        t = c % 27
+        w[c, t // 9, (t % 9) // 3, t % 3] = 1.0 + c // 27
+    b = torch.zeros(96)
+    wd = w.reshape(96, 27).t().contiguous().to(DEV)
+    out = torch.empty(B, R // 2, R // 2, 96, dtype=torch.bfloat16, device=DEV)
+    imd, bd = img.to(DEV), b.to(DEV)
+    _lib.check(lib.fvhd_op_stem_conv(_stream(), _p(imd), _lib.BF16, _p(out), _p(wd), _p(bd), B, R), "stem")
+    torch.cuda.synchronize()
+    want = O.gelu(F.conv2d(img.float(), w, b, stride=2, padding=1))
+    _close(out.permute(0, 3, 1, 2), want, rtol=8e-3, atol_rms=4e-3, what="stem conv one-hot taps")
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])

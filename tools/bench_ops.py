@@ -113,7 +113,71 @@ def bench_attn(B=32):
         print(f"attention N={N:5d} C={Cc:5d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s")
 
 
+def bench_overlap(B=16):
+    """Does the hardware co-schedule an MFMA-bound and a VALU-bound kernel from two streams on the same CUs?
+    fused FFN (C=192: 236 VGPRs, 51 KB LDS) beside dw7x7 (173 VGPRs, 77 KB LDS): sequential vs concurrent time."""
+    Cc, H = 192, 128
+    M, HID = B * H * H, 4 * Cc
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+    X = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+    W1 = (torch.randn(HID, Cc, generator=g) * Cc ** -0.5).to(torch.bfloat16).float().contiguous()
+    W2 = (torch.randn(Cc, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).float().contiguous()
+    nch, che = HID // 32, 32 * Cc
+    i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
+    i2 = torch.empty(nch * che, dtype=torch.bfloat16)
+    _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
+    i1, i2 = i1.to(DEV), i2.to(DEV)
+    b1, b2, ls = torch.zeros(HID, device=DEV), torch.zeros(Cc, device=DEV), torch.full((Cc,), 0.01, device=DEV)
+    x2 = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+    y2 = torch.empty_like(x2)
+    w = torch.randn(49, Cc, device=DEV)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def sp(s):
+        return C.c_void_p(s.cuda_stream)
+
+    def ffn(s, n=4):
+        for _ in range(n):
+            _lib.check(lib.fvhd_op_ffn_fused(sp(s), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc))
+
+    def dw(s, n=4):
+        for _ in range(n):
+            _lib.check(lib.fvhd_op_dwconv(sp(s), p(x2), p(y2), p(w), None, B, H, H, Cc, 7, 1, 1, 0))
+
+    def wall(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream()
+        a.record(cur)
+        s1.wait_event(a)
+        s2.wait_event(a)
+        for _ in range(reps):
+            fn()
+        e1, e2 = torch.cuda.Event(), torch.cuda.Event()
+        e1.record(s1)
+        e2.record(s2)
+        cur.wait_event(e1)
+        cur.wait_event(e2)
+        b.record(cur)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+
+    raw = C.CDLL(_lib.LIB_PATH)
+    for pad in (0, 31 * 1024):
+        raw.fvhd_debug_set_ffn_lds_pad(pad)
+        for _ in range(2):
+            t_f = wall(lambda: ffn(s1))
+            t_d = wall(lambda: dw(s2))
+            t_seq = wall(lambda: (ffn(s1), dw(s1)))
+            t_par = wall(lambda: (ffn(s1), dw(s2)))
+        print(f"overlap test, ffn LDS pad {pad:6d} B (4 launches each): ffn alone {t_f:8.1f} us, dw7 alone {t_d:8.1f} us, "
+              f"same stream {t_seq:8.1f} us, two streams {t_par:8.1f} us")
+    raw.fvhd_debug_set_ffn_lds_pad(0)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "gemm": bench_gemm, "attn": bench_attn}[w]()
+        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
