@@ -172,7 +172,7 @@ struct DwTile {
 template <int K, int S, int MULT, bool ACT, int CS>
 __global__ __launch_bounds__(256) void dwconv_tiled_kernel(
     const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
-    int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int nwg)
+    int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int ntiles, int dbg_mode)
 {
     using T = DwTile<K, S, MULT, ACT, CS>;
     constexpr int PAD = T::PAD, CSI = T::CSI, LPP = T::LPP, LPI = T::LPI, OWT = T::OWT, TW = T::TW, TH = T::TH;
@@ -181,94 +181,124 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(
     bf16* tile = (bf16*)smem;                                   // [IH][IWP][CSI]
     float* lw = (float*)(smem + T::TILE_B);                     // [K*K][CS]
     const int Cout = Cin * MULT;
-
-    const int L = xcd_remap(blockIdx.x, nwg);
-    const int slice = L % nslices;
-    int t = L / nslices;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
-    const int oc0 = slice * CS, ic0 = slice * CSI;
     const int tid = threadIdx.x;
+    const int G = gridDim.x;                                    // persistent workgroups; G % nslices == 0 (launcher)
+    const int L0 = xcd_remap(blockIdx.x, G);
+    const int slice = L0 % nslices;                             // constant over this workgroup's tiles (t = L0 + i*G)
+    const int oc0 = slice * CS, ic0 = slice * CSI;
 
-    // ---- stage the input tile: all loads first, then all LDS writes
-    const int gy0 = ty * TH * S - PAD, gx0 = tx * TW * S - PAD;
-    u32x4 v[NLD];
-    int dst[NLD];
+    for (int i = tid; i < K * K * CS / 4; i += 256) {           // taps of this slice: staged once per workgroup
+        const int e = i * 4, tap = e / CS, c = e - tap * CS;
+        *(f32x4*)&lw[e] = *(const f32x4*)&w[(size_t)tap * Cout + oc0 + c];
+    }
+
+    // per-thread staging slots (compile-time trip count): LDS destination, packed tile-relative (row, col) and channel
+    // offset are tile-independent.  Loads are branch-free: the coordinates are clamped into the image (the address is
+    // always valid, 32-bit element offset from a wave-uniform image base) and the result is zeroed when outside - the
+    // round-1 version spent ~45 instructions of 64-bit address arithmetic plus two branches per 16-B load.
+    int dst[NLD], pyx[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int idx = i * 256 + tid;
         const int cgi = idx % LPI, p = idx / LPI;
         const int iy = p / IW, ix = p - iy * IW;
-        const int gy = gy0 + iy, gx = gx0 + ix;
-        v[i] = u32x4{0u, 0u, 0u, 0u};
+        pyx[i] = (iy << 20) | (ix << 8) | cgi;                 // iy < 128, ix < 4096, cgi < 256
         dst[i] = idx < T::NCHUNK ? ((iy * IWP + ix) * CSI + cgi * 8) * 2 : -1;
-        if (idx < T::NCHUNK && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v[i] = *(const u32x4*)(x + ((size_t)(b * H + gy) * W + gx) * Cin + ic0 + cgi * 8);
     }
-    for (int i = tid; i < K * K * CS / 4; i += 256) {
-        const int e = i * 4, tap = e / CS, c = e - tap * CS;
-        *(f32x4*)&lw[e] = *(const f32x4*)&w[(size_t)tap * Cout + oc0 + c];
-    }
+    u32x4 v[NLD];
+    auto issue_loads = [&](int t) {                             // all 16-B loads of tile t, no waits in between
+        int q = t / nslices;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        const int b = q / tiles_y;
+        const int gy0 = ty * TH * S - PAD, gx0 = tx * TW * S - PAD;
+        const bf16* xb = x + (size_t)b * H * W * Cin + ic0;     // wave-uniform base; per-lane offsets below fit 32 bits
 #pragma unroll
-    for (int i = 0; i < NLD; ++i)
-        if (dst[i] >= 0) *(u32x4*)(smem + dst[i]) = v[i];
-    __syncthreads();
+        for (int i = 0; i < NLD; ++i) {
+            const int gy = gy0 + (pyx[i] >> 20), gx = gx0 + ((pyx[i] >> 8) & 0xfff);
+            const bool ok = dst[i] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && dbg_mode != 2;
+            const unsigned off = ok ? (unsigned)((gy * W + gx) * Cin + (pyx[i] & 0xff) * 8) : 0u;
+            const u32x4 ld = *(const u32x4*)(xb + off);
+            v[i] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
 
     const int cg = tid % LPP, strip = tid / LPP;
     const int r = strip >> 1, xh = strip & 1;
-    const int oy = ty * TH + r, ox0 = tx * TW + xh * OWT;
-    if (oy >= OH || ox0 >= OW) return;
-
-    float acc[OWT][8];
+    float bacc[8];
 #pragma unroll
-    for (int o = 0; o < OWT; ++o)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[o][c] = bias ? bias[oc0 + cg * 8 + c] : 0.0f;
+    for (int c = 0; c < 8; ++c) bacc[c] = bias ? bias[oc0 + cg * 8 + c] : 0.0f;
 
+    if (L0 < ntiles) issue_loads(L0);
+    for (int t = L0; t < ntiles; t += G) {
+        // ---- tile t: registers -> LDS; then the NEXT tile's loads are put in flight before the tap loop, so their HBM
+        //      latency (and this tile's stores) overlap the VALU work instead of adding to it
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (dst[i] >= 0) *(u32x4*)(smem + dst[i]) = v[i];
+        __syncthreads();
+        if (t + G < ntiles) issue_loads(t + G);
+
+        int q = t / nslices;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        const int b = q / tiles_y;
+        const int oy = ty * TH + r, ox0 = tx * TW + xh * OWT;
+        if (oy < OH && ox0 < OW) {
+            float acc[OWT][8];
+#pragma unroll
+            for (int o = 0; o < OWT; ++o)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[o][c] = bacc[c];
 #pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {     // not unrolled: keeps the live set at acc + one tap row + one vector
-        float wr[K][8];
+            for (int ky = 0; ky < (dbg_mode == 1 ? 1 : K); ++ky) {     // not unrolled: keeps the live set at acc + one tap row + one vector
+                float wr[K][8];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const f32x4 w0 = *(const f32x4*)&lw[(ky * K + kx) * CS + cg * 8];
-            const f32x4 w1 = *(const f32x4*)&lw[(ky * K + kx) * CS + cg * 8 + 4];
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x4 w0 = *(const f32x4*)&lw[(ky * K + kx) * CS + cg * 8];
+                    const f32x4 w1 = *(const f32x4*)&lw[(ky * K + kx) * CS + cg * 8 + 4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { wr[kx][c] = w0[c]; wr[kx][4 + c] = w1[c]; }
-        }
-        const bf16* row = tile + ((size_t)(r * S + ky) * IWP + xh * OWT * S) * CSI + cg * CI;
+                    for (int c = 0; c < 4; ++c) { wr[kx][c] = w0[c]; wr[kx][4 + c] = w1[c]; }
+                }
+                const bf16* row = tile + ((size_t)(r * S + ky) * IWP + xh * OWT * S) * CSI + cg * CI;
 #pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-            float vv[CI];
-            if constexpr (CI == 8) {
-                const f32x8 tv = bf8_to_f32(*(const bf16x8*)(row + j * CSI));
+                for (int j = 0; j < NIN; ++j) {
+                    float vv[CI];
+                    if constexpr (CI == 8) {
+                        const f32x8 tv = bf8_to_f32(*(const bf16x8*)(row + j * CSI));
 #pragma unroll
-                for (int c = 0; c < 8; ++c) vv[c] = tv[c];
-            } else {
-                const f32x4 tv = bf4_to_f32(*(const bf16x4*)(row + j * CSI));
+                        for (int c = 0; c < 8; ++c) vv[c] = tv[c];
+                    } else {
+                        const f32x4 tv = bf4_to_f32(*(const bf16x4*)(row + j * CSI));
 #pragma unroll
-                for (int c = 0; c < 4; ++c) vv[c] = tv[c];
-            }
+                        for (int c = 0; c < 4; ++c) vv[c] = tv[c];
+                    }
 #pragma unroll
-            for (int o = 0; o < OWT; ++o) {
-                const int kx = j - o * S;
-                if (kx >= 0 && kx < K) {
+                    for (int o = 0; o < OWT; ++o) {
+                        const int kx = j - o * S;
+                        if (kx >= 0 && kx < K) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[o][c] = __builtin_fmaf(wr[kx][c], vv[c / MULT], acc[o][c]);
+                            for (int c = 0; c < 8; ++c) acc[o][c] = __builtin_fmaf(wr[kx][c], vv[c / MULT], acc[o][c]);
+                        }
+                    }
                 }
             }
+            bf16* yo = y + ((size_t)(b * OH + oy) * OW + ox0) * Cout + oc0 + cg * 8;
+#pragma unroll
+            for (int o = 0; o < OWT; ++o) {
+                if (ox0 + o >= OW) break;
+                f32x8 rr;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rr[c] = ACT ? gelu_erf(acc[o][c]) : acc[o][c];
+                *(bf16x8*)(yo + (size_t)o * Cout) = f32_to_bf8(rr);
+            }
         }
-    }
-    bf16* yo = y + ((size_t)(b * OH + oy) * OW + ox0) * Cout + oc0 + cg * 8;
-#pragma unroll
-    for (int o = 0; o < OWT; ++o) {
-        if (ox0 + o >= OW) break;
-        f32x8 rr;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) rr[c] = ACT ? gelu_erf(acc[o][c]) : acc[o][c];
-        *(bf16x8*)(yo + (size_t)o * Cout) = f32_to_bf8(rr);
+        __syncthreads();           // every wave is done reading the LDS tile before the next one overwrites it
     }
 }
+
+static int g_dw_mode = 0;    // debug (tools/bench_ops.py): 1 = stage + store only (no tap loop), 2 = no staging loads (tap loop on stale LDS)
+extern "C" void fvhd_debug_set_dw_mode(int m) { g_dw_mode = m; }
 
 template <int K, int S, int MULT, bool ACT, int CS>
 static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const float* w, const float* bias,
@@ -277,7 +307,7 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
     using T = DwTile<K, S, MULT, ACT, CS>;
     const int OH = (H + 2 * T::PAD - K) / S + 1, OW = (W + 2 * T::PAD - K) / S + 1;
     const int tiles_x = (OW + T::TW - 1) / T::TW, tiles_y = (OH + T::TH - 1) / T::TH, nslices = Cin * MULT / CS;
-    const int nwg = B * tiles_x * tiles_y * nslices;
+    const int ntiles = B * tiles_x * tiles_y * nslices;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)dwconv_tiled_kernel<K, S, MULT, ACT, CS>,
@@ -285,8 +315,16 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS>), dim3(nwg), dim3(256), T::SHMEM, st, x, y, w, bias,
-                       B, H, W, Cin, OH, OW, tiles_x, tiles_y, nslices, nwg);
+    // persistent workgroups: as many as fit at once (LDS-limited), a multiple of nslices (so that a workgroup's tiles
+    // t = L0 + i*G all belong to one channel slice: taps staged once) and of the 8 XCDs
+    const int per_cu = (int)(160 * 1024 / T::SHMEM) > 0 ? (int)(160 * 1024 / T::SHMEM) : 1;
+    int G = 256 * (per_cu > 4 ? 4 : per_cu);
+    const int q = nslices % 8 == 0 ? nslices : nslices * 8;      // lcm(nslices, 8) for nslices in {1,2,3,4,6,8,12,16,24,48,...}
+    G = (G / q) * q;
+    if (G <= 0) G = q;
+    if (ntiles <= 3 * G) G = ((ntiles + nslices - 1) / nslices) * nslices;   // few rounds: one tile per workgroup (dynamic balance beats persistence)
+    hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS>), dim3(G), dim3(256), T::SHMEM, st, x, y, w, bias,
+                       B, H, W, Cin, OH, OW, tiles_x, tiles_y, nslices, ntiles, g_dw_mode);
     return hipGetLastError();
 }
 

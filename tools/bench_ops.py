@@ -70,7 +70,17 @@ def bench_ffn(B=32, variants=True):
                 print(f"    NB={nb} waves={wv} variant {v:2d} pf={pf} ({names[v]:26s}): {tv*1e6:9.1f} us  {fl/tv/1e12:7.1f} TF/s")
 
 
-def bench_dw(B=32):
+def bench_dw(B=32, modes=(0,)):
+    raw = C.CDLL(_lib.LIB_PATH)
+    for mode in modes:
+        raw.fvhd_debug_set_dw_mode(mode)
+        if mode:
+            print(f"--- dw debug mode {mode} ({'stage + store only' if mode == 1 else 'no staging loads'})")
+        _bench_dw(B)
+    raw.fvhd_debug_set_dw_mode(0)
+
+
+def _bench_dw(B=32):
     for K, S, mult, gelu, Cc, H in ((3, 1, 1, 0, 96, 256), (3, 1, 1, 0, 192, 128), (3, 1, 1, 0, 384, 64),
                                     (7, 1, 1, 0, 96, 256), (7, 1, 1, 0, 192, 128), (7, 1, 1, 0, 384, 64),
                                     (7, 1, 1, 0, 768, 32), (7, 1, 1, 0, 1536, 16),
@@ -180,4 +190,4 @@ def bench_overlap(B=16):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
+        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
