@@ -89,6 +89,30 @@ def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True):
     return {k: tuple(v) for k, v in w.items()}
 
 
+def pmc_traffic(kernel_class: str):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (`profiles/*_pmc_summary.json`,
+    collected with separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B read requests at 64 B).  None if no such profile is in the tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    prof = json.load(open(files[-1]))
+    parts = {"ffn_fused": [("ffn_fused_kernelILi384E", 24), ("ffn_fused_kernelILi192E", 12), ("ffn_fused_kernelILi96E", 2)],
+             "dw7": [("dwconv_tiled_kernelILi7ELi1ELi1ELb0ELi64E", 44), ("dwconv_tiled_kernelILi7ELi1ELi1ELb0ELi32E", 2)],
+             "dw3": [("dwconv_tiled_kernelILi3ELi1ELi1ELb0ELi64E", 36), ("dwconv_tiled_kernelILi3ELi1ELi1ELb0ELi32E", 2)]}.get(kernel_class)
+    if not parts:
+        return None, None
+    tot, n = 0.0, 0
+    for sub, launches in parts:
+        hit = [v for k, v in prof.items() if sub in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+        if not hit:
+            return None, None
+        tot += launches * 1024.0 * (2.0 * hit[0]["FETCH_SIZE"]["per_dispatch"] + hit[0]["WRITE_SIZE"]["per_dispatch"])
+        n += launches
+    return tot / n, os.path.relpath(files[-1], ROOT)
+
+
 GEMM_CLASSES = {"gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv", "gemm_proj", "attention", "projector", "ffn_fused"}
 
 
@@ -248,6 +272,11 @@ def main():
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                   "avg_launch_ms": round(avg_ms, 4), "bytes_per_launch": work[dom][1] / n_dom}
+        traffic, src = pmc_traffic(dom)
+        result["roofline"]["traffic"] = None if traffic is None else round(traffic)
+        result["roofline"]["traffic_note"] = (None if traffic is None else
+                                              f"HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, {src}); algorithmic bytes per launch "
+                                              f"{work[dom][1] / n_dom:.4g}")
         result["kernels"] = table
         result["kernel_ms_per_step_profiled"] = round(total_ms, 3)
         tot_fl = sum(v[0] for v in work.values())
