@@ -204,12 +204,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     const int uwave = __builtin_amdgcn_readfirstlane(wave);          // provably uniform: DMA bases stay in SGPRs / M0
     const unsigned lds_w1 = __builtin_amdgcn_readfirstlane(lds_addr(w1ring)), lds_w2 = __builtin_amdgcn_readfirstlane(lds_addr(w2ring));
 
-#pragma unroll
-    for (int g = 0; g < (NG + WAVES - 1) / WAVES; ++g) {             // W1[0]
-        const int piece = g * WAVES + uwave;
-        if (NG % WAVES == 0 || piece < NG)
-            glds16(w1img + piece * 1024 + lane * 16, lds_w1 + piece * 1024);
-    }
     for (int i = tid; i < HID / 4; i += WAVES * 64) *(f32x4*)&lb1[i * 4] = *(const f32x4*)&b1[i * 4];
 
     // per-lane fragment pointers (ring slot 0), see ffn_iter
@@ -224,13 +218,50 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     f32x16 o[NB][NFR];
     f32x16 s0[NB], s1[NB];          // s[k&1] holds S(k)
     bf16x8 p0[NB][2], p1[NB][2];    // p[k&1] holds P(k)
-    // ---- A^T fragments (B operands), straight from global: lane reads 16 B of its own row per k-step
+    // ---- A^T fragments (B operands).  A wave's 32 rows are 32*C*2 contiguous bytes of HBM, but the MFMA wants lane
+    // (row, k-half) to hold 16 B of ITS row: loading that directly is 32 rows x 32 B per instruction (a quarter of every
+    // 128-B line per request; the prologue + epilogue were 26-50 % of this kernel's time in the round-1 ablation).
+    // Instead the tile is read fully coalesced (lane L of load i takes 16-B chunk i*64+L) and transposed through LDS -
+    // the (still empty) weight rings - with a 16-B-slot XOR swizzle that keeps both sides conflict-free.
+    static_assert(NB == 1 && WAVES == 4, "the LDS transpose uses one quarter of the 4*CHB ring area per wave");
+    constexpr int CPR = C / 8;               // 16-B chunks per row
+    constexpr int NL = 32 * CPR / 64;        // coalesced 16-B loads per lane for one 32-row tile (== KS)
+    constexpr int SH = C == 384 ? 4 : C == 192 ? 3 : 2, SWZ = (1 << SH) - 1;
+    // chunk id (= row * CPR + chunk-in-row; the tile is contiguous in HBM, so id*16 is also its byte offset) -> LDS byte
+    // offset.  The XOR key (id >> SH) & SWZ equals (3*row + const) mod 2^SH for the rows of one fragment read (CPR = 3 * 2^SH),
+    // a bijection on row mod 2^SH: the 16 lanes of a ds_read_b128 group land in 16 different 16-B slots.
+    auto slot_of = [](int id) { return (id ^ ((id >> SH) & SWZ)) << 4; };
+    char* stage = smem + wave * (32 * C * 2);
+    const size_t tile_b = (size_t)row0 * C * 2, last_b = (size_t)M * C * 2 - 16;     // rows >= M: any valid address (never stored)
+    constexpr bool CIO = C <= 192;           // C = 384: measured slower (register spills in the edges, serialised W1[0] DMA)
+    if constexpr (CIO) {
+        u32x4 t[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const size_t gb = tile_b + (size_t)(i * 64 + lane) * 16;
+            t[i] = *(const u32x4*)((const char*)A + (gb < last_b ? gb : last_b));
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) *(u32x4*)(stage + slot_of(i * 64 + lane)) = t[i];
+        // same wave wrote and reads: LDS operations of one wave are processed in order, no barrier needed
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afr[0][ks] = *(const bf16x8*)(stage + slot_of(li * CPR + ks * 2 + half));
+    } else {
+        // straight from global: lane reads 16 B of its own row per k-step
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int m_ld = min(row0 + nb * 32 + li, M - 1);
         const bf16* arow = A + (size_t)m_ld * C + half * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) afr[nb][ks] = *(const bf16x8*)(arow + ks * 16);
+    }
+    }
+    if constexpr (CIO) __syncthreads();      // every wave has its fragments: the rings may now receive weights
+#pragma unroll
+    for (int g = 0; g < (NG + WAVES - 1) / WAVES; ++g) {             // W1[0]
+        const int piece = g * WAVES + uwave;
+        if (NG % WAVES == 0 || piece < NG)
+            glds16(w1img + piece * 1024 + lane * 16, lds_w1 + piece * 1024);
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -263,9 +294,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
         FFN_SYNC();                  // odd t:  S(t) -> s1, GELU(s0 + b1[t-1]) -> p0, GEMM2 reads p1
         ffn_iter<C, NB, WAVES, true, true, true, DMA, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + t * 32, half, FFN_DMA_ARGS(t + 1));
     }
-    // the residual rows of X are fetched now (the A^T registers are dead from here on) so that their HBM latency hides
-    // behind the last two pipeline iterations instead of stalling the epilogue
+    // the residual tile of X is fetched now, coalesced like A^T above (the A^T registers are dead from here on), so that
+    // its HBM latency hides behind the last two pipeline iterations instead of stalling the epilogue
+    u32x4 xq[CIO ? NL : 1];
     bf16x4 xres[NB][NFR][4];
+    if constexpr (CIO) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const size_t gb = tile_b + (size_t)(i * 64 + lane) * 16;
+            xq[i] = *(const u32x4*)((const char*)X + (gb < last_b ? gb : last_b));
+        }
+    } else {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const bf16* xrd = X + (size_t)min(row0 + nb * 32 + li, M - 1) * C + 4 * half;
@@ -274,6 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 #pragma unroll
             for (int q = 0; q < 4; ++q) xres[nb][nf][q] = *(const bf16x4*)(xrd + nf * 32 + 8 * q);
     }
+    }
     FFN_SYNC();                      // t = NCH (even): GELU(S(NCH-1) in s1) -> p1, GEMM2(chunk NCH-2) reads p0; DMA W2[NCH-1]
     ffn_iter<C, NB, WAVES, false, true, true, true, VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1 + (NCH - 1) * 32, half, FFN_DMA_ARGS(NCH));
     FFN_SYNC();                      // t = NCH + 1: GEMM2(chunk NCH-1) reads p1
@@ -281,6 +321,34 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 #undef FFN_DMA_ARGS
 #undef FFN_SYNC
 
+    // ---- epilogue.  The accumulators are in MFMA layout (lane = row li, 4 consecutive channels n0 = nf*32 + 8q + 4*half per
+    // register quad); X and the output want the coalesced layout.  Two trips through the (now idle) ring area of this wave:
+    // X: coalesced registers -> LDS -> MFMA layout;  x + ls * (o + b2) in fp32, ONE rounding to bf16 -> LDS -> coalesced store.
+    if constexpr (CIO) {
+    __syncthreads();                         // all waves are done reading the weight rings
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *(u32x4*)(stage + slot_of(i * 64 + lane)) = xq[i];
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n0 = nf * 32 + 8 * q + 4 * half;
+            char* slot = stage + slot_of(li * CPR + nf * 4 + q) + half * 8;
+            const f32x4 bv = *(const f32x4*)(b2 + n0), lv = *(const f32x4*)(ls + n0);
+            const f32x4 rv = bf4_to_f32(*(const bf16x4*)slot);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = rv[j] + lv[j] * (o[0][nf][4 * q + j] + bv[j]);
+            *(bf16x4*)slot = f32_to_bf4(v);
+        }
+    const int rows_ok = M - row0;            // rows of this tile that exist
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int id = i * 64 + lane;
+        const u32x4 v = *(const u32x4*)(stage + slot_of(id));
+        if (id < rows_ok * CPR) *(u32x4*)((char*)X + tile_b + (size_t)id * 16) = v;
+    }
+    } else {
     // ---- epilogue: lane holds out[m][n0 .. n0+3], n0 = nf*32 + 8q + 4*half -------------------------
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -300,6 +368,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
                     *(bf16x4*)(xr + n0) = f32_to_bf4(v);
                 }
         }
+    }
     }
 }
 
@@ -390,12 +459,11 @@ extern "C" int fvhd_debug_ffn_variant(hipStream_t st, const void* A, const void*
     bf16* x = (bf16*)X;
     hipError_t e = hipErrorInvalidValue;
 #define V(CC, NN, WW, VV, PP) if (C == CC && nb == NN && waves == WW && variant == VV && pf == PP) e = launch_ffn<CC, NN, WW, VV, PP>(st, a, w1, w2, b1, b2, ls, x, M);
-    V(384, 1, 4, 0, 3) V(384, 1, 4, 3, 3) V(384, 1, 4, 15, 3) V(384, 1, 4, 16, 3) V(192, 2, 4, 16, 3) V(192, 1, 8, 16, 3) V(96, 1, 8, 16, 3)
-    V(192, 1, 8, 0, 3) V(192, 2, 4, 0, 3) V(192, 2, 4, 0, 2) V(192, 2, 4, 3, 3) V(192, 2, 4, 1, 3) V(192, 2, 4, 2, 3) V(192, 2, 4, 12, 3)
-    V(96, 1, 8, 0, 3) V(96, 2, 4, 0, 3) V(96, 2, 4, 2, 3) V(96, 2, 4, 3, 3)
-    if (C == 192 && nb == 1 && waves == 4 && pf == 3) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);   // 2 workgroups / CU
-    if (C == 96 && nb == 1 && waves == 4 && pf == 3) e = launch_ffn<96, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
-    if (C == 96 && nb == 1 && waves == 4 && pf == 2) e = launch_ffn<96, 1, 4, 0, 2, 3>(st, a, w1, w2, b1, b2, ls, x, M);   // 3 workgroups / CU
+    V(384, 1, 4, 0, 3) V(384, 1, 4, 3, 3) V(384, 1, 4, 15, 3) V(384, 1, 4, 16, 3)
+    if (C == 192 && nb == 1 && waves == 4 && pf == 3 && variant == 0) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);   // 2 workgroups / CU
+    if (C == 192 && nb == 1 && waves == 4 && pf == 3 && variant == 16) e = launch_ffn<192, 1, 4, 16, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
+    if (C == 96 && nb == 1 && waves == 4 && pf == 3 && variant == 0) e = launch_ffn<96, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
+    if (C == 96 && nb == 1 && waves == 4 && pf == 3 && variant == 16) e = launch_ffn<96, 1, 4, 16, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
 #undef V
     return (int)e;
 }

@@ -1,10 +1,11 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r01b -o trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_bench.log 2>&1
-FVHD_DUAL=0 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-FVHD_DUAL=0 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-FVHD_DUAL=0 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/pmc_sq -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-cd $R; ls gpurun_out/prof_r01b gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq; tail -2 gpurun_out/prof_bench.log | cut -c1-300
+timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_steps.py -x -q 2>&1 | tail -3
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench.json'))
+print(d['value'], d['ms_per_step'], d['roofline'])
+for k,v in d['kernels'].items(): print(k, v)
+PY

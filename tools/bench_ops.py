@@ -63,8 +63,8 @@ def bench_ffn(B=32, variants=True):
             f.argtypes = [C.c_void_p] * 8 + [C.c_int] * 6
             names = {0: "full", 1: "no weight DMA", 2: "no GELU", 3: "no DMA, no GELU", 12: "no MFMA", 13: "no MFMA, no DMA", 15: "LDS reads + barriers only", 16: "prologue + 4 edge iterations + epilogue only"}
             combos = {384: [(1, 4, 0, 3), (1, 4, 3, 3), (1, 4, 15, 3), (1, 4, 16, 3)],
-                      192: [(1, 8, 0, 3), (2, 4, 0, 3), (2, 4, 0, 2), (2, 4, 3, 3), (2, 4, 1, 3), (1, 4, 0, 3), (2, 4, 16, 3), (1, 8, 16, 3)],
-                      96: [(1, 8, 0, 3), (2, 4, 0, 3), (1, 4, 0, 3), (1, 4, 0, 2), (1, 8, 16, 3)]}[Cc]
+                      192: [(1, 4, 0, 3), (1, 4, 16, 3)],
+                      96: [(1, 4, 0, 3), (1, 4, 16, 3)]}[Cc]
             for nb, wv, v, pf in combos:
                 tv = timeit(lambda: f(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc, nb, wv, v, pf))
                 print(f"    NB={nb} waves={wv} variant {v:2d} pf={pf} ({names[v]:26s}): {tv*1e6:9.1f} us  {fl/tv/1e12:7.1f} TF/s")
