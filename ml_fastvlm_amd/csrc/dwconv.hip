@@ -150,14 +150,14 @@ static hipError_t launch_dw(hipStream_t st, const bf16* x, bf16* y, const float*
 //   * tiles are ordered (slice fastest, then x, y, image) inside one 1-D grid and XCD-remapped, so the channel slices
 //     of a pixel and the halo-sharing neighbours run on the same XCD / L2: the halo re-reads (1.6-1.9x the tile) are
 //     L2 hits, HBM sees every input byte about once.
-template <int K, int S, int MULT, bool ACT, int CS>
+template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false>
 struct DwTile {
     static constexpr int PAD = K / 2;
     static constexpr int CSI = CS / MULT;            // input channels per slice
     static constexpr int LPP = CS / 8;               // lanes per output pixel (8 output channels each)
     static constexpr int LPI = CSI / 8;              // 16-B chunks per input pixel
     static constexpr int NSTRIP = 256 / LPP;         // strips per workgroup
-    static constexpr int OWT = S == 1 ? 8 : 4;       // output pixels per strip
+    static constexpr int OWT = (S == 1 && !OW4) ? 8 : 4;   // output pixels per strip
     static constexpr int TW = 2 * OWT, TH = NSTRIP / 2;
     static constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K;
     static constexpr int IWP = IW | 1;               // odd row stride (pixels)
@@ -169,12 +169,12 @@ struct DwTile {
     static constexpr size_t SHMEM = TILE_B + (size_t)K * K * CS * 4;
 };
 
-template <int K, int S, int MULT, bool ACT, int CS>
-__global__ __launch_bounds__(256) void dwconv_tiled_kernel(
+template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, bool PREF = true>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void dwconv_tiled_kernel(
     const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
     int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int ntiles, int dbg_mode)
 {
-    using T = DwTile<K, S, MULT, ACT, CS>;
+    using T = DwTile<K, S, MULT, ACT, CS, OW4>;
     constexpr int PAD = T::PAD, CSI = T::CSI, LPP = T::LPP, LPI = T::LPI, OWT = T::OWT, TW = T::TW, TH = T::TH;
     constexpr int IW = T::IW, IWP = T::IWP, NIN = T::NIN, CI = T::CI, NLD = T::NLD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,15 +229,18 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(
 #pragma unroll
     for (int c = 0; c < 8; ++c) bacc[c] = bias ? bias[oc0 + cg * 8 + c] : 0.0f;
 
-    if (L0 < ntiles) issue_loads(L0);
+    // PREF: the next tile's loads ride in registers across the tap loop (costs NLD*4 VGPRs); otherwise they are issued
+    // at the top of the tile and the other resident workgroups cover their latency
+    if (PREF && L0 < ntiles) issue_loads(L0);
     for (int t = L0; t < ntiles; t += G) {
+        if (!PREF) issue_loads(t);
         // ---- tile t: registers -> LDS; then the NEXT tile's loads are put in flight before the tap loop, so their HBM
         //      latency (and this tile's stores) overlap the VALU work instead of adding to it
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             if (dst[i] >= 0) *(u32x4*)(smem + dst[i]) = v[i];
         __syncthreads();
-        if (t + G < ntiles) issue_loads(t + G);
+        if (PREF && t + G < ntiles) issue_loads(t + G);
 
         int q = t / nslices;
         const int tx = q % tiles_x; q /= tiles_x;
@@ -297,20 +300,22 @@ __global__ __launch_bounds__(256) void dwconv_tiled_kernel(
     }
 }
 
+static int g_dw7_cfg = 1;    // debug: 1 = per-C choice, 3 = always 64-channel slices / 8-pixel strips, other = always 32 / 4
+extern "C" void fvhd_debug_set_dw7_cfg(int m) { g_dw7_cfg = m; }
 static int g_dw_mode = 0;    // debug (tools/bench_ops.py): 1 = stage + store only (no tap loop), 2 = no staging loads (tap loop on stale LDS)
 extern "C" void fvhd_debug_set_dw_mode(int m) { g_dw_mode = m; }
 
-template <int K, int S, int MULT, bool ACT, int CS>
+template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, bool PREF = true>
 static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const float* w, const float* bias,
                                   int B, int H, int W, int Cin)
 {
-    using T = DwTile<K, S, MULT, ACT, CS>;
+    using T = DwTile<K, S, MULT, ACT, CS, OW4>;
     const int OH = (H + 2 * T::PAD - K) / S + 1, OW = (W + 2 * T::PAD - K) / S + 1;
     const int tiles_x = (OW + T::TW - 1) / T::TW, tiles_y = (OH + T::TH - 1) / T::TH, nslices = Cin * MULT / CS;
     const int ntiles = B * tiles_x * tiles_y * nslices;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwconv_tiled_kernel<K, S, MULT, ACT, CS>,
+        hipError_t e = hipFuncSetAttribute((const void*)dwconv_tiled_kernel<K, S, MULT, ACT, CS, OW4, WPE, PREF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SHMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -323,7 +328,7 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
     G = (G / q) * q;
     if (G <= 0) G = q;
     if (ntiles <= 3 * G) G = ((ntiles + nslices - 1) / nslices) * nslices;   // few rounds: one tile per workgroup (dynamic balance beats persistence)
-    hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS>), dim3(G), dim3(256), T::SHMEM, st, x, y, w, bias,
+    hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS, OW4, WPE, PREF>), dim3(G), dim3(256), T::SHMEM, st, x, y, w, bias,
                        B, H, W, Cin, OH, OW, tiles_x, tiles_y, nslices, ntiles, g_dw_mode);
     return hipGetLastError();
 }
@@ -337,14 +342,25 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     const int Cout = Cin * mult;
     hipError_t e = hipErrorInvalidValue;
     const bool c64 = Cout % 64 == 0, c32 = Cout % 32 == 0;
-    // hot variants: LDS-tiled kernel; 64-output-channel slices when they divide Cout, else 32
+    // dw7x7 stride 1 (46 launches, VALU-bound): 32-channel slices, 4-pixel strips, 32x8 tiles -> 43 KB LDS and <= 170
+    // VGPRs, i.e. 3 workgroups (12 waves) per CU instead of 2: a wave64 VALU instruction issues every ~4 cycles per wave
+    // but executes in ~2.3, so the pipe only saturates with >= 3 waves per SIMD (tools/ubench/valu_rate.hip)
+    if (K == 7 && stride == 1 && mult == 1 && !gelu && c32) {
+        // measured per channel count (tools/bench_ops.py dw7cfg, B = 32): 32-channel slices / 4-pixel strips / 3 waves per
+        // SIMD win at C = 96, 384, 768; 64-channel slices / 8-pixel strips / 2 waves per SIMD at C = 192 and >= 1536.
+        // Neither carries the next tile's loads in registers across the tap loop: with them the kernel needs > 256
+        // registers, i.e. ONE wave per SIMD (or scratch spills) - that cost more than the prefetch bought.
+        const bool wide = c64 && (g_dw7_cfg == 3 || (g_dw7_cfg == 1 && (Cin == 192 || Cin >= 1536)));
+        if (wide) return (int)launch_dw_tiled<7, 1, 1, false, 64, false, 2, false>(st, xi, yo, w, bias, B, H, W, Cin);
+        return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 3, false>(st, xi, yo, w, bias, B, H, W, Cin);
+    }
 #define DW_TILED(KK, SS, MM, AA)                                                                          \
     if (K == KK && stride == SS && mult == MM && (gelu != 0) == AA && c32) {                              \
         e = c64 ? launch_dw_tiled<KK, SS, MM, AA, 64>(st, xi, yo, w, bias, B, H, W, Cin)                  \
                 : launch_dw_tiled<KK, SS, MM, AA, 32>(st, xi, yo, w, bias, B, H, W, Cin);                 \
         return (int)e;                                                                                    \
     }
-    DW_TILED(3, 1, 1, false) DW_TILED(7, 1, 1, false) DW_TILED(7, 2, 2, true) DW_TILED(3, 2, 1, true) DW_TILED(3, 1, 2, false)
+    DW_TILED(3, 1, 1, false) DW_TILED(7, 2, 2, true) DW_TILED(3, 2, 1, true) DW_TILED(3, 1, 2, false)
 #undef DW_TILED
     if (K == 3 && stride == 1 && mult == 1 && !gelu) e = launch_dw<3, 1, 1, false>(st, xi, yo, w, bias, B, H, W, Cin);
     else if (K == 3 && stride == 2 && mult == 1 && gelu) e = launch_dw<3, 2, 1, true>(st, xi, yo, w, bias, B, H, W, Cin);

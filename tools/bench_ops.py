@@ -80,12 +80,23 @@ def bench_dw(B=32, modes=(0,)):
     raw.fvhd_debug_set_dw_mode(0)
 
 
-def _bench_dw(B=32):
+def bench_dw7cfg():
+    raw = C.CDLL(_lib.LIB_PATH)
+    for cfg in (1, 2, 3):
+        raw.fvhd_debug_set_dw7_cfg(cfg)
+        print(f"--- dw7 config {cfg}")
+        _bench_dw(32, only_k7=True)
+    raw.fvhd_debug_set_dw7_cfg(1)
+
+
+def _bench_dw(B=32, only_k7=False):
     for K, S, mult, gelu, Cc, H in ((3, 1, 1, 0, 96, 256), (3, 1, 1, 0, 192, 128), (3, 1, 1, 0, 384, 64),
                                     (7, 1, 1, 0, 96, 256), (7, 1, 1, 0, 192, 128), (7, 1, 1, 0, 384, 64),
                                     (7, 1, 1, 0, 768, 32), (7, 1, 1, 0, 1536, 16),
                                     (7, 2, 2, 1, 96, 256), (7, 2, 2, 1, 192, 128), (7, 2, 2, 1, 384, 64), (7, 2, 2, 1, 768, 32),
                                     (3, 2, 1, 1, 96, 512)):
+        if only_k7 and not (K == 7 and S == 1):
+            continue
         OH = H // S
         x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
         y = torch.empty(B, OH, OH, Cc * mult, device=DEV, dtype=torch.bfloat16)
@@ -190,4 +201,4 @@ def bench_overlap(B=16):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
+        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "dw7cfg": bench_dw7cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
