@@ -7,8 +7,9 @@
 // wave64 butterfly reductions) and the qkv GEMM output [B*N, 3C] already has q/k/v of head h at
 // column offsets h*32, C + h*32, 2C + h*32 - attention reads it in place with a row stride of 3C.
 //
-// Attention kernel (flash-style, one (image, head, 64-query block) per 256-thread workgroup):
-//   * each wave owns 16 queries; Q fragment lives in registers (one 16-B load per lane).
+// Attention kernel (flash-style, one (image, head, 128-query block) per 256-thread workgroup):
+//   * each wave owns 2 x 16 queries (every K / V^T fragment read from LDS feeds two MFMAs: the 16x16x32 fragment is 1 KiB
+//     per 16-cycle MFMA, i.e. the whole LDS bandwidth at one query block per wave); Q fragments live in registers.
 //   * K/V stream through LDS in 64-key tiles, double buffered; K tile row-major [64][32] with the
 //     same XOR slot swizzle as the GEMM (conflict-free ds_read_b128 fragment reads); V is stored
 //     TRANSPOSED in LDS ([32 d][64 keys], 136-B row stride -> conflict-free ds_read_b64) because the
@@ -87,7 +88,8 @@ extern "C" int fvhd_launch_layernorm(hipStream_t st, const void* x, void* y, con
 // ---------------------------------------------------------------------------------------------------
 #define ATT_D 32
 #define ATT_KT 64          // keys per tile
-#define ATT_QB 64          // queries per workgroup (16 per wave)
+#define ATT_QW 2           // 16-query blocks per wave: every K / V^T fragment read from LDS feeds ATT_QW MFMAs
+#define ATT_QB (64 * ATT_QW)   // queries per workgroup
 #define ATT_VT_STRIDE 136  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
 
 __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
@@ -100,9 +102,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const size_t row_stride = (size_t)3 * C;
     const bf16* base = qkv + (size_t)b * N * row_stride + h * ATT_D;
 
-    // Q fragment (B operand: n = query = lr, k = d = 8g..8g+7)
-    const int q_idx = qb * ATT_QB + wave * 16 + lr;
-    const bf16x8 qf = *(const bf16x8*)(base + (size_t)min(q_idx, N - 1) * row_stride + g * 8);
+    // Q fragments (B operand: n = query = lr, k = d = 8g..8g+7), ATT_QW blocks of 16 queries per wave
+    int q_idx[ATT_QW];
+    bf16x8 qf[ATT_QW];
+#pragma unroll
+    for (int w = 0; w < ATT_QW; ++w) {
+        q_idx[w] = qb * ATT_QB + (wave * ATT_QW + w) * 16 + lr;
+        qf[w] = *(const bf16x8*)(base + (size_t)min(q_idx[w], N - 1) * row_stride + g * 8);
+    }
 
     // staging assignment: thread -> (key = tid>>2, 16-B chunk = tid&3) of the K and V tiles
     const int skey = tid >> 2, sch = tid & 3;
@@ -110,8 +117,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const bf16* vptr = base + 2 * C + sch * 8;
     const int k_dst = skey * 64 + ((sch ^ ((0 - (skey >> 2)) & 3)) << 4);
 
-    f32x4 o_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // O^T[d = df*16 + 4g + r][q = lr]
-    float m_run = -1e30f, l_run = 0.f;
+    f32x4 o_acc[ATT_QW][2];                              // O^T[d = df*16 + 4g + r][q = lr]
+    float m_run[ATT_QW], l_run[ATT_QW];
+#pragma unroll
+    for (int w = 0; w < ATT_QW; ++w) {
+        o_acc[w][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        o_acc[w][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[w] = -1e30f;
+        l_run[w] = 0.f;
+    }
 
     const int ntiles = (N + ATT_KT - 1) / ATT_KT;
     u32x4 rk, rv;
@@ -136,67 +150,79 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             rv = *(const u32x4*)(vptr + (size_t)key * row_stride);
         }
 
-        // S^T[key][q] for 4 key fragments of 16
-        f32x4 s[4];
-        float mx = -1e30f;
+        // S^T[key][q] for 4 key fragments of 16: one K fragment read per fragment, used by every query block
+        f32x4 s[ATT_QW][4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
             const int krow = kf * 16 + lr;
             const bf16x8 kfr = *(const bf16x8*)(kbuf + krow * 64 + ((g ^ ((0 - (krow >> 2)) & 3)) << 4));
-            s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * ATT_KT + kf * 16 + g * 4 + r;
-                if (key >= N) s[kf][r] = -1e30f;
-                mx = fmaxf(mx, s[kf][r]);
-            }
+            for (int w = 0; w < ATT_QW; ++w)
+                s[w][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[w], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pf[2];     // B operand of O^T = V^T . P^T: n = q = lr, k-slot j <-> key (j<4 ? 4g+j : 16+4g+j-4) of chunk c
+        const bool ragged = (t + 1) * ATT_KT > N;
+        bf16x8 pf[ATT_QW][2];   // B operand of O^T = V^T . P^T: n = q = lr, k-slot j <-> key (j<4 ? 4g+j : 16+4g+j-4) of chunk c
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            f32x8 p;
+        for (int w = 0; w < ATT_QW; ++w) {
+            float mx = -1e30f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = __builtin_amdgcn_exp2f((s[2 * c][r] - m_new) * scale_log2e);
-                p[4 + r] = __builtin_amdgcn_exp2f((s[2 * c + 1][r] - m_new) * scale_log2e);
-            }
+            for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) psum += p[r];
-            pf[c] = f32_to_bf8(p);
-        }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int df = 0; df < 2; ++df) {
-            o_acc[df] *= alpha;
+                for (int r = 0; r < 4; ++r) {
+                    if (ragged && t * ATT_KT + kf * 16 + g * 4 + r >= N) s[w][kf][r] = -1e30f;
+                    mx = fmaxf(mx, s[w][kf][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[w], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[w] - m_new) * scale_log2e);
+            m_run[w] = m_new;
+            const float mb = m_new * scale_log2e;
+            float psum = 0.f;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                // A operand: row = d = df*16 + lr, k-slot j <-> same key permutation as pf
+                f32x8 p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c][r], scale_log2e, -mb));
+                    p[4 + r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c + 1][r], scale_log2e, -mb));
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) psum += p[r];
+                pf[w][c] = f32_to_bf8(p);
+            }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[w] = l_run[w] * alpha + psum;
+            o_acc[w][0] *= alpha;
+            o_acc[w][1] *= alpha;
+        }
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // A operand: row = d = df*16 + lr, k-slot j <-> same key permutation as pf; one read feeds every query block
                 const char* vr = vbuf + (df * 16 + lr) * ATT_VT_STRIDE + (c * 32 + g * 4) * 2;
                 const bf16x4 lo = *(const bf16x4*)(vr);
                 const bf16x4 hi = *(const bf16x4*)(vr + 32);
                 const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                o_acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], o_acc[df], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < ATT_QW; ++w)
+                    o_acc[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[w][c], o_acc[w][df], 0, 0, 0);
             }
-        }
         // no second barrier: the next iteration writes the OTHER buffer, and the buffer written two
         // iterations from now is only touched after every wave has passed the next __syncthreads().
     }
 
-    if (q_idx < N) {
-        const float inv = 1.0f / l_run;
-        bf16* orow = out + ((size_t)b * N + q_idx) * C + h * ATT_D;
 #pragma unroll
-        for (int df = 0; df < 2; ++df)
-            *(bf16x4*)(orow + df * 16 + g * 4) = f32_to_bf4(o_acc[df] * inv);
-    }
+    for (int w = 0; w < ATT_QW; ++w)
+        if (q_idx[w] < N) {
+            const float inv = 1.0f / l_run[w];
+            bf16* orow = out + ((size_t)b * N + q_idx[w]) * C + h * ATT_D;
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+                *(bf16x4*)(orow + df * 16 + g * 4) = f32_to_bf4(o_acc[w][df] * inv);
+        }
 }
 
 // qkv [B*N, 3C] bf16 (q | k | v, head h at columns h*32) -> out [B*N, C] bf16.  C % 32 == 0.
