@@ -313,12 +313,14 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
     const int OH = (H + 2 * T::PAD - K) / S + 1, OW = (W + 2 * T::PAD - K) / S + 1;
     const int tiles_x = (OW + T::TW - 1) / T::TW, tiles_y = (OH + T::TH - 1) / T::TH, nslices = Cin * MULT / CS;
     const int ntiles = B * tiles_x * tiles_y * nslices;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {false};      // the attribute is per device: one flag per HIP device of this process
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
         hipError_t e = hipFuncSetAttribute((const void*)dwconv_tiled_kernel<K, S, MULT, ACT, CS, OW4, WPE, PREF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SHMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev & 63] = true;
     }
     // persistent workgroups: as many as fit at once (LDS-limited), a multiple of nslices (so that a workgroup's tiles
     // t = L0 + i*G all belong to one channel slice: taps staged once) and of the 8 XCDs

@@ -382,11 +382,13 @@ static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, c
     constexpr int ROWS = 32 * NB * WAVES;
     const int nwg = (M + ROWS - 1) / ROWS;
     const size_t shmem = (size_t)4 * 64 * C + (size_t)4 * C * 4 + 256 + g_ffn_lds_pad;   // + pad: the last bias prefetch reads one chunk past b1
-    static int attr_set = -1;
-    if (attr_set != g_ffn_lds_pad) {
+    static int attr_set[64];                 // the attribute is per device: last size set on each HIP device (+1; 0 = never)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (attr_set[dev & 63] != g_ffn_lds_pad + 1) {
         hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        attr_set = g_ffn_lds_pad;
+        attr_set[dev & 63] = g_ffn_lds_pad + 1;
     }
     hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
     return hipGetLastError();

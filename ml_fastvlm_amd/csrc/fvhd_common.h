@@ -31,19 +31,19 @@ FVHD_DEV bf16x4 f32_to_bf4(f32x4 v) { return __builtin_convertvector(v, bf16x4);
 // erfc(z), z >= 0, by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below bf16 resolution):
 //   erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z).
 // This is the *erf* GELU the reference uses (nn.GELU() default, mci.py:108/387/870), not the tanh form.
+// Written for minimum VALU issue slots (11 full-rate VALU + v_rcp + v_exp):  gelu(x) = max(x, 0) - |x| * Phi(-|x|).
 FVHD_DEV float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    q = __builtin_fmaf(q, t, 1.421413741f);
-    q = __builtin_fmaf(q, t, -0.284496736f);
-    q = __builtin_fmaf(q, t, 0.254829592f);
-    q = q * t;
-    // exp(-z^2) = exp2(-x^2 * 0.5 * log2(e))
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
-    const float half_erfc = 0.5f * q * e;                 // = 0.5 * erfc(|x|/sqrt2) = Phi(-|x|)
-    const float phi = x >= 0.0f ? 1.0f - half_erfc : half_erfc;
-    return x * phi;
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+    float q = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    q = __builtin_fmaf(q, t, 0.5f * 1.421413741f);
+    q = __builtin_fmaf(q, t, 0.5f * -0.284496736f);
+    q = __builtin_fmaf(q, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((x * -0.72134752044448170f) * x);      // exp(-x^2 / 2)
+    const float h = (q * t) * e;                                                   // Phi(-|x|) = 0.5 erfc(|x| / sqrt 2)
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));          // relu without the canonicalising self-max that fmaxf() costs
+    return __builtin_fmaf(-ax, h, r);
 }
 
 FVHD_DEV float sigmoidf_fast(float x) {
