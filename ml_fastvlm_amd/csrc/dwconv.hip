@@ -169,17 +169,17 @@ struct DwTile {
     static constexpr size_t SHMEM = TILE_B + (size_t)K * K * CS * 4;
 };
 
-template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, bool PREF = true>
+template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, int PREF = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void dwconv_tiled_kernel(
     const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
     int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int ntiles, int dbg_mode)
 {
     using T = DwTile<K, S, MULT, ACT, CS, OW4>;
     constexpr int PAD = T::PAD, CSI = T::CSI, LPP = T::LPP, LPI = T::LPI, OWT = T::OWT, TW = T::TW, TH = T::TH;
-    constexpr int IW = T::IW, IWP = T::IWP, NIN = T::NIN, CI = T::CI, NLD = T::NLD;
+    constexpr int IW = T::IW, IWP = T::IWP, NIN = T::NIN, CI = T::CI, NLD = T::NLD, IH_ = T::IH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* tile = (bf16*)smem;                                   // [IH][IWP][CSI]
-    float* lw = (float*)(smem + T::TILE_B);                     // [K*K][CS]
+    bf16* tile = (bf16*)smem;                                   // [IH][IWP][CSI] (x2 when PREF == 2)
+    float* lw = (float*)(smem + (PREF == 2 ? 2 : 1) * T::TILE_B);   // [K*K][CS]
     const int Cout = Cin * MULT;
     const int tid = threadIdx.x;
     const int G = gridDim.x;                                    // persistent workgroups; G % nslices == 0 (launcher)
@@ -196,16 +196,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // offset are tile-independent.  Loads are branch-free: the coordinates are clamped into the image (the address is
     // always valid, 32-bit element offset from a wave-uniform image base) and the result is zeroed when outside - the
     // round-1 version spent ~45 instructions of 64-bit address arithmetic plus two branches per 16-B load.
-    int dst[NLD], pyx[NLD];
+    // PREF == 2 (LDS-DMA): slot i of a lane is 16-B chunk i*256 + tid of the PADDED LDS image (a wave's 64 chunks are
+    // 1 KiB contiguous - what one global_load_lds_dwordx4 writes); pad-column chunks are never read and load anything.
+    constexpr bool DMA = PREF == 2;
+    constexpr int NSL = DMA ? (IH_ * IWP * LPI + 255) / 256 : NLD;
+    int dst[NSL], pyx[NSL];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
+    for (int i = 0; i < NSL; ++i) {
         const int idx = i * 256 + tid;
         const int cgi = idx % LPI, p = idx / LPI;
-        const int iy = p / IW, ix = p - iy * IW;
+        const int RW = DMA ? IWP : IW;
+        const int iy = p / RW, ix = p - iy * RW;
         pyx[i] = (iy << 20) | (ix << 8) | cgi;                 // iy < 128, ix < 4096, cgi < 256
-        dst[i] = idx < T::NCHUNK ? ((iy * IWP + ix) * CSI + cgi * 8) * 2 : -1;
+        if (DMA) dst[i] = idx < IH_ * IWP * LPI ? (ix < IW ? idx * 16 : -2) : -1;    // -2: pad column, -1: past the image
+        else dst[i] = idx < T::NCHUNK ? ((iy * IWP + ix) * CSI + cgi * 8) * 2 : -1;
     }
-    u32x4 v[NLD];
+    u32x4 v[DMA ? 1 : NLD];
     auto issue_loads = [&](int t) {                             // all 16-B loads of tile t, no waits in between
         int q = t / nslices;
         const int tx = q % tiles_x; q /= tiles_x;
@@ -222,6 +228,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             v[i] = ok ? ld : u32x4{0u, 0u, 0u, 0u};
         }
     };
+    // LDS-DMA staging of tile t into the tile buffer at LDS byte address `base`: no registers carry the data, so the
+    // next tile's loads fly during the whole tap loop at full occupancy.  The DMA cannot zero-fill: chunks outside the
+    // image load a valid dummy address and are zeroed by their owner lane after the DMA has landed (returned bit mask).
+    // Address = wave-uniform SGPR image base + 32-bit per-lane byte offset (saddr form: no 64-bit VALU arithmetic);
+    // the per-slot part of the offset is tile-independent (soffb), so an interior tile costs one v_add per 16-B chunk.
+    const unsigned lds_tile0 = __builtin_amdgcn_readfirstlane(lds_addr(smem) + (tid >> 6) * 1024);
+    int soffb[DMA ? NSL : 1];
+    unsigned vmask = 0;                                         // bit i: slot i is a real (non-pad, in-tile) chunk
+    bool last_live = true;                                      // the last slot may run past the LDS image: lane masked off
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int iy = pyx[i] >> 20, ix = (pyx[i] >> 8) & 0xfff;
+            const int ixc = ix < IW ? ix : IW - 1;              // pad column: re-load the last real pixel (never read)
+            soffb[i] = dst[i] == -1 ? 0 : ((iy * W + ixc) * Cin + (pyx[i] & 0xff) * 8) * 2;
+            vmask |= dst[i] >= 0 ? (1u << i) : 0u;
+        }
+        last_live = dst[NSL - 1] != -1;
+    }
+    auto issue_dma = [&](int t, unsigned base) -> unsigned {
+        int q = t / nslices;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        const int b = q / tiles_y;
+        const int gy0 = ty * TH * S - PAD, gx0 = tx * TW * S - PAD;
+        const bf16* xb = x + (size_t)b * H * W * Cin + ic0;
+        const int t0b = (gy0 * W + gx0) * Cin * 2;              // may be negative; t0b + soffb >= 0 for chunks inside the image
+        unsigned zm = 0;
+        if (gy0 >= 0 && gx0 >= 0 && gy0 + IH_ <= H && gx0 + IW <= W) {          // interior tile (wave-uniform branch)
+#pragma unroll
+            for (int i = 0; i < NSL; ++i)
+                if (i < NSL - 1 || last_live) glds16_s(xb, (unsigned)(t0b + soffb[i]), base + i * 4096);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int gy = gy0 + (pyx[i] >> 20), gx = gx0 + ((pyx[i] >> 8) & 0xfff);
+                const bool ok = ((vmask >> i) & 1) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                if (i < NSL - 1 || last_live) glds16_s(xb, ok ? (unsigned)(t0b + soffb[i]) : 0u, base + i * 4096);
+                zm |= (((vmask >> i) & 1) && !ok) ? (1u << i) : 0u;
+            }
+        }
+        return zm;
+    };
 
     const int cg = tid % LPP, strip = tid / LPP;
     const int r = strip >> 1, xh = strip & 1;
@@ -229,18 +278,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
     for (int c = 0; c < 8; ++c) bacc[c] = bias ? bias[oc0 + cg * 8 + c] : 0.0f;
 
-    // PREF: the next tile's loads ride in registers across the tap loop (costs NLD*4 VGPRs); otherwise they are issued
-    // at the top of the tile and the other resident workgroups cover their latency
-    if (PREF && L0 < ntiles) issue_loads(L0);
+    // PREF 1: the next tile's loads ride in registers across the tap loop (costs NLD*4 VGPRs); PREF 0: they are issued
+    // at the top of the tile and the other resident workgroups cover their latency; PREF 2: LDS-DMA into the other of
+    // two LDS tile buffers during the tap loop (one barrier per tile)
+    unsigned zm_cur = 0, cur = 0;
+    if (PREF == 1 && L0 < ntiles) issue_loads(L0);
+    if (DMA && L0 < ntiles && dbg_mode != 2) zm_cur = issue_dma(L0, lds_tile0);
     for (int t = L0; t < ntiles; t += G) {
-        if (!PREF) issue_loads(t);
-        // ---- tile t: registers -> LDS; then the NEXT tile's loads are put in flight before the tap loop, so their HBM
-        //      latency (and this tile's stores) overlap the VALU work instead of adding to it
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // tile t has landed in buffer `cur`
+            if (zm_cur) {                                                       // border tiles only
 #pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (dst[i] >= 0) *(u32x4*)(smem + dst[i]) = v[i];
-        __syncthreads();
-        if (PREF && t + G < ntiles) issue_loads(t + G);
+                for (int i = 0; i < NSL; ++i)
+                    if ((zm_cur >> i) & 1) *(u32x4*)(smem + cur * T::TILE_B + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
+            __syncthreads();                                                    // ... and every wave left buffer cur^1
+            zm_cur = 0;
+            if (t + G < ntiles && dbg_mode != 2) zm_cur = issue_dma(t + G, lds_tile0 + (cur ^ 1) * (unsigned)T::TILE_B);
+            tile = (bf16*)(smem + cur * T::TILE_B);
+            cur ^= 1;
+        } else {
+            if (PREF == 0) issue_loads(t);
+            // ---- tile t: registers -> LDS; then the NEXT tile's loads are put in flight before the tap loop, so their
+            //      HBM latency (and this tile's stores) overlap the VALU work instead of adding to it
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                if (dst[i] >= 0) *(u32x4*)(smem + dst[i]) = v[i];
+            __syncthreads();
+            if (PREF == 1 && t + G < ntiles) issue_loads(t + G);
+        }
 
         int q = t / nslices;
         const int tx = q % tiles_x; q /= tiles_x;
@@ -253,17 +319,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             for (int o = 0; o < OWT; ++o)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) acc[o][c] = bacc[c];
+            const bf16* row = tile + ((r * S) * IWP + xh * OWT * S) * CSI + cg * CI;     // advanced by one tile row per ky
+            const float* lwp = lw + cg * 8;                                                // ... and by one tap row
 #pragma unroll 1
-            for (int ky = 0; ky < (dbg_mode == 1 ? 1 : K); ++ky) {     // not unrolled: keeps the live set at acc + one tap row + one vector
+            for (int ky = 0; ky < (dbg_mode == 1 ? 1 : K); ++ky, row += IWP * CSI, lwp += K * CS) {   // not unrolled: keeps the live set at acc + one tap row + one vector
                 float wr[K][8];
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
-                    const f32x4 w0 = *(const f32x4*)&lw[(ky * K + kx) * CS + cg * 8];
-                    const f32x4 w1 = *(const f32x4*)&lw[(ky * K + kx) * CS + cg * 8 + 4];
+                    const f32x4 w0 = *(const f32x4*)&lwp[kx * CS];
+                    const f32x4 w1 = *(const f32x4*)&lwp[kx * CS + 4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { wr[kx][c] = w0[c]; wr[kx][4 + c] = w1[c]; }
                 }
-                const bf16* row = tile + ((size_t)(r * S + ky) * IWP + xh * OWT * S) * CSI + cg * CI;
 #pragma unroll
                 for (int j = 0; j < NIN; ++j) {
                     float vv[CI];
@@ -296,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 *(bf16x8*)(yo + (size_t)o * Cout) = f32_to_bf8(rr);
             }
         }
-        __syncthreads();           // every wave is done reading the LDS tile before the next one overwrites it
+        if constexpr (!DMA) __syncthreads();   // every wave is done reading the LDS tile before the next one overwrites it
     }
 }
 
@@ -305,7 +372,7 @@ extern "C" void fvhd_debug_set_dw7_cfg(int m) { g_dw7_cfg = m; }
 static int g_dw_mode = 0;    // debug (tools/bench_ops.py): 1 = stage + store only (no tap loop), 2 = no staging loads (tap loop on stale LDS)
 extern "C" void fvhd_debug_set_dw_mode(int m) { g_dw_mode = m; }
 
-template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, bool PREF = true>
+template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, int PREF = 1>
 static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const float* w, const float* bias,
                                   int B, int H, int W, int Cin)
 {
@@ -313,24 +380,25 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
     const int OH = (H + 2 * T::PAD - K) / S + 1, OW = (W + 2 * T::PAD - K) / S + 1;
     const int tiles_x = (OW + T::TW - 1) / T::TW, tiles_y = (OH + T::TH - 1) / T::TH, nslices = Cin * MULT / CS;
     const int ntiles = B * tiles_x * tiles_y * nslices;
+    const size_t SHMEM = T::SHMEM + (PREF == 2 ? T::TILE_B : 0);
     static bool attr_set[64] = {false};      // the attribute is per device: one flag per HIP device of this process
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
         hipError_t e = hipFuncSetAttribute((const void*)dwconv_tiled_kernel<K, S, MULT, ACT, CS, OW4, WPE, PREF>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::SHMEM);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SHMEM);
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = true;
     }
     // persistent workgroups: as many as fit at once (LDS-limited), a multiple of nslices (so that a workgroup's tiles
     // t = L0 + i*G all belong to one channel slice: taps staged once) and of the 8 XCDs
-    const int per_cu = (int)(160 * 1024 / T::SHMEM) > 0 ? (int)(160 * 1024 / T::SHMEM) : 1;
+    const int per_cu = (int)(160 * 1024 / SHMEM) > 0 ? (int)(160 * 1024 / SHMEM) : 1;
     int G = 256 * (per_cu > 4 ? 4 : per_cu);
     const int q = nslices % 8 == 0 ? nslices : nslices * 8;      // lcm(nslices, 8) for nslices in {1,2,3,4,6,8,12,16,24,48,...}
     G = (G / q) * q;
     if (G <= 0) G = q;
     if (ntiles <= 3 * G) G = ((ntiles + nslices - 1) / nslices) * nslices;   // few rounds: one tile per workgroup (dynamic balance beats persistence)
-    hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS, OW4, WPE, PREF>), dim3(G), dim3(256), T::SHMEM, st, x, y, w, bias,
+    hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS, OW4, WPE, PREF>), dim3(G), dim3(256), SHMEM, st, x, y, w, bias,
                        B, H, W, Cin, OH, OW, tiles_x, tiles_y, nslices, ntiles, g_dw_mode);
     return hipGetLastError();
 }
@@ -348,13 +416,15 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // VGPRs, i.e. 3 workgroups (12 waves) per CU instead of 2: a wave64 VALU instruction issues every ~4 cycles per wave
     // but executes in ~2.3, so the pipe only saturates with >= 3 waves per SIMD (tools/ubench/valu_rate.hip)
     if (K == 7 && stride == 1 && mult == 1 && !gelu && c32) {
-        // measured per channel count (tools/bench_ops.py dw7cfg, B = 32): 32-channel slices / 4-pixel strips / 3 waves per
-        // SIMD win at C = 96, 384, 768; 64-channel slices / 8-pixel strips / 2 waves per SIMD at C = 192 and >= 1536.
-        // Neither carries the next tile's loads in registers across the tap loop: with them the kernel needs > 256
-        // registers, i.e. ONE wave per SIMD (or scratch spills) - that cost more than the prefetch bought.
-        const bool wide = c64 && (g_dw7_cfg == 3 || (g_dw7_cfg == 1 && (Cin == 192 || Cin >= 1536)));
-        if (wide) return (int)launch_dw_tiled<7, 1, 1, false, 64, false, 2, false>(st, xi, yo, w, bias, B, H, W, Cin);
-        return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 3, false>(st, xi, yo, w, bias, B, H, W, Cin);
+        // measured per channel count (tools/bench_ops.py dw7cfg, B = 32, us): config 4 = 32-channel slices / 4-pixel strips,
+        // two LDS tile buffers filled by LDS-DMA during the tap loop, 2 waves per SIMD: 445 / 246 / 118 at C = 96 / 192 / 384
+        // (2 = same tile, register staging, 3 waves per SIMD: 485 / 268 / 128).  From C = 768 on there are too few tiles
+        // per workgroup for the prefetch to matter: config 2 at 768 (64), 64-channel slices / 8-pixel strips at >= 1536 (34).
+        const bool wide = c64 && (g_dw7_cfg == 3 || (g_dw7_cfg == 1 && Cin >= 1536));
+        const bool dma = g_dw7_cfg == 4 || (g_dw7_cfg == 1 && Cin <= 384);
+        if (dma) return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 2, 2>(st, xi, yo, w, bias, B, H, W, Cin);
+        if (wide) return (int)launch_dw_tiled<7, 1, 1, false, 64, false, 2, 0>(st, xi, yo, w, bias, B, H, W, Cin);
+        return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 3, 0>(st, xi, yo, w, bias, B, H, W, Cin);
     }
 #define DW_TILED(KK, SS, MM, AA)                                                                          \
     if (K == KK && stride == SS && mult == MM && (gelu != 0) == AA && c32) {                              \

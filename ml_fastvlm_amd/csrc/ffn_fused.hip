@@ -46,22 +46,32 @@ __host__ __device__ __forceinline__ int w2_off(int row, int slot)               
     return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
 }
 
-// exact-erf GELU, 14 VALU issue slots, cut into six half-stages of 2-3 VALU; the software pipeline below advances two
-// hidden values (independent dependency chains) by one half-stage per MFMA slot:
-//   gelu(x) = max(x, 0) - |x| * Phi(-|x|),   Phi(-|x|) = 0.5 erfc(|x| / sqrt 2)  (A&S 7.1.26, |err| <= 1.5e-7)
-struct GeluSt { float x, u, t, z, q, e; };
-template <int H> FVHD_DEV void gelu_half(GeluSt& g, float s, float b, float& out)
+// erf GELU (fvhd_common.h: Phi(x) = 0.5 + xc Q(xc^2)) on PAIRS of hidden values: every step is one v_pk_*_f32, so a pair
+// costs 13 packed + 2 v_med3 issue slots (7.5 per value; the A&S form of round 1 took 14).  Cut into six half-stages of
+// 2-4 instructions; the software pipeline below advances one pair by one half-stage per unit.
+struct GeluSt { f32x2 x, xc, u, q; };
+#define FFN_PK(c) (f32x2{c, c})
+template <int H> FVHD_DEV void gelu_half(GeluSt& g, f32x2 s, f32x2 b, f32x2& out)
 {
-    if constexpr (H == 0) { g.x = s + b; g.u = __builtin_fmaf(0.3275911f * 0.70710678118654752f, fabsf(g.x), 1.0f); }
-    else if constexpr (H == 1) { g.t = __builtin_amdgcn_rcpf(g.u); g.z = (g.x * -0.72134752044448170f) * g.x; }   // z = -x^2/2 * log2(e)
-    else if constexpr (H == 2) { g.e = __builtin_amdgcn_exp2f(g.z); g.q = __builtin_fmaf(0.5f * 1.061405429f, g.t, 0.5f * -1.453152027f); }
-    else if constexpr (H == 3) { g.q = __builtin_fmaf(g.q, g.t, 0.5f * 1.421413741f); g.q = __builtin_fmaf(g.q, g.t, 0.5f * -0.284496736f); }
-    else if constexpr (H == 4) { g.q = __builtin_fmaf(g.q, g.t, 0.5f * 0.254829592f); g.q = g.q * g.t; }
-    else {
-        const float h = g.q * g.e;                          // Phi(-|x|)
-        float r;
-        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(g.x));    // relu without the canonicalising self-max fmaxf() costs
-        out = __builtin_fmaf(-fabsf(g.x), h, r);
+    if constexpr (H == 0) {
+        g.x = s + b;
+        g.xc = f32x2{__builtin_amdgcn_fmed3f(g.x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(g.x[1], -4.0f, 4.0f)};
+    } else if constexpr (H == 1) {
+        g.u = g.xc * g.xc;
+        g.q = __builtin_elementwise_fma(FFN_PK(FVHD_GELU_C9), g.u, FFN_PK(FVHD_GELU_C8));
+    } else if constexpr (H == 2) {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C7));
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C6));
+    } else if constexpr (H == 3) {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C5));
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C4));
+    } else if constexpr (H == 4) {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C3));
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C2));
+    } else {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C1));
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C0));
+        out = g.x * __builtin_elementwise_fma(g.xc, g.q, FFN_PK(0.5f));
     }
 }
 
@@ -71,14 +81,7 @@ template <int H> FVHD_DEV void gelu_half(GeluSt& g, float s, float b, float& out
 // builtin, 0 with it), which exposes the full LDS latency before every MFMA.  hipcc does not count an asm load, so the
 // consumer side waits explicitly: s_waitcnt vmcnt(0) before the barrier that publishes the images (ffn_wait_dma).
 // M0 is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md 5.7).
-FVHD_DEV void glds16(const void* gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 FVHD_DEV void ffn_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-FVHD_DEV unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
 
 // One pipeline iteration t, for the NB 32-row blocks a wave owns:
 //     s_out <- GEMM1(chunk t);   p_out <- GELU(s_in + b1 = S(t-1));   O += GEMM2(chunk t-2, p_in = P(t-2)).
@@ -108,8 +111,8 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
 #define FFN_LD_ON(f) (((f) & 1) ? DO_C : DO_A)
     bf16x8 wf[NF];
     f32x4 bv[4];
-    GeluSt gs[NB][16];
-    float gout[NB][16];
+    GeluSt gs[NB][8];
+    f32x2 gout[NB][8];
     if constexpr (DO_B) bv[0] = *(const f32x4*)(b1_prev + 4 * half);
 #pragma unroll
     for (int f = 0; f < PF; ++f)
@@ -153,21 +156,21 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
             for (int q = 1; q < 4; ++q)     // bias of values 4q..4q+3 (first used by unit 24*q*NB): read ~2 slots ahead
                 if (m == ((24 * q * NB) / UPS >= 2 ? (24 * q * NB) / UPS - 2 : 0)) bv[q] = *(const f32x4*)(b1_prev + 8 * q + 4 * half);
 #pragma unroll
-            for (int u = m * UPS; u < (m + 1) * UPS; ++u) {     // unit u = (((pair j, half-stage h), block gb), member w)
-                const int w = u & 1, gb = (u >> 1) % NB, jh = (u >> 1) / NB, h = jh % 6, r = 2 * (jh / 6) + w;
+            for (int u = m * UPS / 2; u < (m + 1) * UPS / 2; ++u) {     // unit u = ((pair j, half-stage h), block gb)
+                const int gb = u % NB, jh = u / NB, h = jh % 6, r = 2 * (jh / 6);
+                const f32x2 sv = {s_in[gb][r], s_in[gb][r + 1]}, bb = {bv[r >> 2][r & 3], bv[r >> 2][(r & 3) + 1]};
                 if (VAR & 2) {               // ablation bit 1: no GELU math
-                    if (h == 5) gout[gb][r] = s_in[gb][r] + bv[r >> 2][r & 3];
+                    if (h == 5) gout[gb][r >> 1] = sv + bb;
                 } else {
-                    const float sv = s_in[gb][r], bb = bv[r >> 2][r & 3];
-                    if (h == 0) gelu_half<0>(gs[gb][r], sv, bb, gout[gb][r]);
-                    else if (h == 1) gelu_half<1>(gs[gb][r], sv, bb, gout[gb][r]);
-                    else if (h == 2) gelu_half<2>(gs[gb][r], sv, bb, gout[gb][r]);
-                    else if (h == 3) gelu_half<3>(gs[gb][r], sv, bb, gout[gb][r]);
-                    else if (h == 4) gelu_half<4>(gs[gb][r], sv, bb, gout[gb][r]);
-                    else gelu_half<5>(gs[gb][r], sv, bb, gout[gb][r]);
+                    if (h == 0) gelu_half<0>(gs[gb][r >> 1], sv, bb, gout[gb][r >> 1]);
+                    else if (h == 1) gelu_half<1>(gs[gb][r >> 1], sv, bb, gout[gb][r >> 1]);
+                    else if (h == 2) gelu_half<2>(gs[gb][r >> 1], sv, bb, gout[gb][r >> 1]);
+                    else if (h == 3) gelu_half<3>(gs[gb][r >> 1], sv, bb, gout[gb][r >> 1]);
+                    else if (h == 4) gelu_half<4>(gs[gb][r >> 1], sv, bb, gout[gb][r >> 1]);
+                    else gelu_half<5>(gs[gb][r >> 1], sv, bb, gout[gb][r >> 1]);
                 }
-                if (h == 5 && (r & 3) == 3) {
-                    const bf16x4 pk = f32_to_bf4(f32x4{gout[gb][r - 3], gout[gb][r - 2], gout[gb][r - 1], gout[gb][r]});
+                if (h == 5 && (r & 3) == 2) {
+                    const bf16x4 pk = f32_to_bf4(f32x4{gout[gb][(r >> 1) - 1][0], gout[gb][(r >> 1) - 1][1], gout[gb][r >> 1][0], gout[gb][r >> 1][1]});
 #pragma unroll
                     for (int j = 0; j < 4; ++j) p_out[gb][r >> 3][(r & 4) + j] = pk[j];
                 }
