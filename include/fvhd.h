@@ -106,6 +106,12 @@ int fvhd_run_steps(fvhd_ctx* ctx, int first, int last, const void* x_in, int bat
  * "stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv", "gemm_proj",
  * "layernorm", "attention", "head", "projector", "ffn_fused". */
 int fvhd_profile_enable(fvhd_ctx* ctx, int on);
+
+/* Precision option of the MHSA core (mci.py:670-679) for BASELINE.json configs[4] ("fp8 MFMA attention path"):
+ * on != 0 runs QK^T and PV with e4m3 operands (fvhd_op_attention_fp8) in every AttentionBlock of fvhd_encode /
+ * fvhd_run_steps; default 0 = bf16 operands (the parity path).  The reference has no such switch: its attention runs in
+ * the tower dtype (mobileclip_encoder.py:85).  Also settable with the environment variable FVHD_ATTN_FP8=1 at fvhd_create. */
+int fvhd_set_attention_fp8(fvhd_ctx* ctx, int on);
 int fvhd_profile_reset(fvhd_ctx* ctx);
 int fvhd_profile_read(fvhd_ctx* ctx, int max_classes, const char** names, double* ms, int64_t* launches,
                       int* n_classes);
@@ -122,6 +128,8 @@ int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const floa
 int fvhd_op_layernorm(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* b, int M, int C, float eps);
 /* MHSA core (mci.py:670-679): qkv [B*N,3C] bf16 -> out [B*N,C] bf16, head_dim 32. */
 int fvhd_op_attention(fvhd_stream_t stream, const void* qkv, void* out, int B, int N, int C);
+/* same, Q/K/V and P = exp(s - max) rounded to OCP e4m3 (RNE) as MFMA operands, fp32 accumulation and softmax statistics. */
+int fvhd_op_attention_fp8(fvhd_stream_t stream, const void* qkv, void* out, int B, int N, int C);
 /* stem[0] (mci.py:563-574): img [B,3,R,R] of dtype -> out [B,R/2,R/2,96] bf16; w fp32 [27][96] (k = ci*9+ky*3+kx). */
 int fvhd_op_stem_conv(fvhd_stream_t stream, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R);
 /* SEBlock + GELU of conv_exp (mci.py:72-81,198): y [B,T,C] bf16 -> out [B,T,C] of out_dtype;

@@ -369,6 +369,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
 static int g_dw7_cfg = 1;    // debug: 1 = per-C choice, 3 = always 64-channel slices / 8-pixel strips, other = always 32 / 4
 extern "C" void fvhd_debug_set_dw7_cfg(int m) { g_dw7_cfg = m; }
+static int g_dw3_cfg = 0;    // debug: 0 = register-prefetch tiles (64|32-channel slices, 8-pixel strips), 1/2 = LDS-DMA double buffer, 32/64-channel slices, 4-pixel strips
+extern "C" void fvhd_debug_set_dw3_cfg(int m) { g_dw3_cfg = m; }
 static int g_dw_mode = 0;    // debug (tools/bench_ops.py): 1 = stage + store only (no tap loop), 2 = no staging loads (tap loop on stale LDS)
 extern "C" void fvhd_debug_set_dw_mode(int m) { g_dw_mode = m; }
 
@@ -425,6 +427,10 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
         if (dma) return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 2, 2>(st, xi, yo, w, bias, B, H, W, Cin);
         if (wide) return (int)launch_dw_tiled<7, 1, 1, false, 64, false, 2, 0>(st, xi, yo, w, bias, B, H, W, Cin);
         return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 3, 0>(st, xi, yo, w, bias, B, H, W, Cin);
+    }
+    if (K == 3 && stride == 1 && mult == 1 && !gelu && c32 && g_dw3_cfg) {
+        if (g_dw3_cfg == 2 && c64) return (int)launch_dw_tiled<3, 1, 1, false, 64, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
+        return (int)launch_dw_tiled<3, 1, 1, false, 32, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
     }
 #define DW_TILED(KK, SS, MM, AA)                                                                          \
     if (K == KK && stride == SS && mult == MM && (gelu != 0) == AA && c32) {                              \

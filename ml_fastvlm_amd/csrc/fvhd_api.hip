@@ -18,7 +18,7 @@ extern "C" {
 int fvhd_launch_dwconv(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
-int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int);
+int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int, int);
 int fvhd_launch_stem_conv(hipStream_t, const void*, int, void*, const float*, const float*, int, int);
 int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, const float*, const float*, const float*,
                         void*, int, int, int, int, int);
@@ -140,6 +140,7 @@ struct fvhd_ctx {
     // through the whole tower, and the MFMA-heavy ConvFFN kernels of one half co-run on the CUs with the VALU-bound
     // depthwise kernels / HBM-bound prologues of the other.  aux joins back into the caller's stream before returning.
     int dual = 1;
+    int attn_fp8 = 0;            // fvhd_set_attention_fp8 / FVHD_ATTN_FP8=1: e4m3 MFMA operands in MHSA (BASELINE.json configs[4])
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
@@ -389,7 +390,7 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
         if ((e = run_gemm(c, st, C_QKV, c->wdev, blk.qkv, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_NONE))) return e;
         {
             Scope s(c, st, C_ATT);
-            CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C), "attention launch");
+            CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C, c->attn_fp8), "attention launch");
         }
         if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID))) return e;
         return run_ffn(c, st, blk.ffn, w, X, B, H, H, C);
@@ -519,6 +520,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_DUAL")) c->dual = atoi(ev);
+    if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
     *out = c;
     return 0;
 }
@@ -732,6 +734,13 @@ int fvhd_run_steps(fvhd_ctx* c, int first, int last, const void* x_in, int batch
 int fvhd_num_tokens(const fvhd_ctx* c) { return c ? (c->R / 64) * (c->R / 64) : 0; }
 int fvhd_hidden_size(const fvhd_ctx* c) { (void)c; return kOutDim; }
 
+int fvhd_set_attention_fp8(fvhd_ctx* c, int on)
+{
+    if (!c) return fail("fvhd_set_attention_fp8: ctx is NULL");
+    c->attn_fp8 = on != 0;
+    return 0;
+}
+
 int fvhd_profile_enable(fvhd_ctx* c, int on)
 {
     if (!c) return fail("fvhd_profile_enable: ctx is NULL");
@@ -798,8 +807,14 @@ int fvhd_op_layernorm(fvhd_stream_t st, const void* x, void* y, const float* w, 
 
 int fvhd_op_attention(fvhd_stream_t st, const void* qkv, void* out, int B, int N, int C)
 {
-    int e = fvhd_launch_attention((hipStream_t)st, qkv, out, B, N, C);
+    int e = fvhd_launch_attention((hipStream_t)st, qkv, out, B, N, C, 0);
     return e ? hip_fail("fvhd_op_attention", (hipError_t)e) : 0;
+}
+
+int fvhd_op_attention_fp8(fvhd_stream_t st, const void* qkv, void* out, int B, int N, int C)
+{
+    int e = fvhd_launch_attention((hipStream_t)st, qkv, out, B, N, C, 1);
+    return e ? hip_fail("fvhd_op_attention_fp8", (hipError_t)e) : 0;
 }
 
 int fvhd_op_stem_conv(fvhd_stream_t st, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R)

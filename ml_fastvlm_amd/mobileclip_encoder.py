@@ -91,6 +91,9 @@ class MobileCLIPVisionTower(nn.Module):
         self.vision_tower_name = vision_tower
         self.tune_vision_tower = getattr(args, "unfreeze_mm_vision_tower", False)
         self.input_image_size = int(vision_tower.split("_")[-1])
+        # MI355X-only option (no counterpart in the reference): e4m3 MFMA operands in the MHSA core, the "fp8 MFMA attention
+        # path" of BASELINE.json configs[4]; read from the config object like the reference reads its own switches
+        self.attention_fp8 = bool(getattr(args, "mm_vision_attention_fp8", False))
         self._ctx: Optional[_lib.Context] = None
         self._ctx_key = None
         self._dirty = True
@@ -158,6 +161,7 @@ class MobileCLIPVisionTower(nn.Module):
                     self._ctx.set_tensor(k, v)
             self._ctx.finalize()
             self._dirty = False
+        self._ctx.set_attention_fp8(self.attention_fp8)
         return self._ctx
 
     def sync_weights(self) -> None:

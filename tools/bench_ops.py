@@ -80,6 +80,27 @@ def bench_dw(B=32, modes=(0,)):
     raw.fvhd_debug_set_dw_mode(0)
 
 
+def bench_dw3cfg():
+    raw = C.CDLL(_lib.LIB_PATH)
+    for cfg in (0, 1, 2):
+        raw.fvhd_debug_set_dw3_cfg(cfg)
+        print(f"--- dw3 config {cfg}")
+        _bench_dw(32, only_k3=True)
+    for Cc, H, B in ((96, 37, 3), (192, 20, 2), (384, 64, 2), (768, 9, 5), (96, 256, 2)):
+        x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+        w = torch.randn(9, Cc, device=DEV)
+        bias = torch.randn(Cc, device=DEV)
+        outs = []
+        for cfg in (0, 1, 2):
+            raw.fvhd_debug_set_dw3_cfg(cfg)
+            y = torch.full((B, H, H, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
+            _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 3, 1, 1, 0))
+            torch.cuda.synchronize()
+            outs.append(y.clone())
+        print(f"dw3 cfg agreement C={Cc} H={H} B={B}:", [bool(torch.equal(outs[0], o)) for o in outs[1:]])
+    raw.fvhd_debug_set_dw3_cfg(0)
+
+
 def bench_dw7cfg():
     raw = C.CDLL(_lib.LIB_PATH)
     for cfg in (1, 2, 3, 4):
@@ -102,13 +123,15 @@ def bench_dw7cfg():
     raw.fvhd_debug_set_dw7_cfg(1)
 
 
-def _bench_dw(B=32, only_k7=False):
+def _bench_dw(B=32, only_k7=False, only_k3=False):
     for K, S, mult, gelu, Cc, H in ((3, 1, 1, 0, 96, 256), (3, 1, 1, 0, 192, 128), (3, 1, 1, 0, 384, 64),
                                     (7, 1, 1, 0, 96, 256), (7, 1, 1, 0, 192, 128), (7, 1, 1, 0, 384, 64),
                                     (7, 1, 1, 0, 768, 32), (7, 1, 1, 0, 1536, 16),
                                     (7, 2, 2, 1, 96, 256), (7, 2, 2, 1, 192, 128), (7, 2, 2, 1, 384, 64), (7, 2, 2, 1, 768, 32),
                                     (3, 2, 1, 1, 96, 512)):
         if only_k7 and not (K == 7 and S == 1):
+            continue
+        if only_k3 and not (K == 3 and S == 1):
             continue
         OH = H // S
         x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
@@ -214,4 +237,4 @@ def bench_overlap(B=16):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "dw7cfg": bench_dw7cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
+        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
