@@ -112,6 +112,13 @@ int fvhd_profile_enable(fvhd_ctx* ctx, int on);
  * fvhd_run_steps; default 0 = bf16 operands (the parity path).  The reference has no such switch: its attention runs in
  * the tower dtype (mobileclip_encoder.py:85).  Also settable with the environment variable FVHD_ATTN_FP8=1 at fvhd_create. */
 int fvhd_set_attention_fp8(fvhd_ctx* ctx, int on);
+
+/* hipGraph replay: on != 0 makes fvhd_encode / fvhd_encode_images capture the interior steps of the tower (everything between
+ * the stem, which reads the caller's images, and the head, which writes the caller's buffer: ~170 launches on two streams)
+ * into one hipGraph per (batch, options) on the second call with that batch size and replay it from then on - the launch-bound
+ * small-batch case (TTFT, B = 1..8).  The reference's analogue is none (eager PyTorch, mobileclip_encoder.py:70-88).
+ * A caller that is itself stream-capturing gets plain launches.  Also FVHD_GRAPH=1 at fvhd_create.  Default off. */
+int fvhd_set_graph(fvhd_ctx* ctx, int on);
 int fvhd_profile_reset(fvhd_ctx* ctx);
 int fvhd_profile_read(fvhd_ctx* ctx, int max_classes, const char** names, double* ms, int64_t* launches,
                       int* n_classes);

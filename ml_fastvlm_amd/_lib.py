@@ -48,6 +48,7 @@ def _declare(lib) -> None:
         "fvhd_op_attention": (ci, [vp, vp, vp, ci, ci, ci]),
         "fvhd_op_attention_fp8": (ci, [vp, vp, vp, ci, ci, ci]),
         "fvhd_set_attention_fp8": (ci, [vp, ci]),
+        "fvhd_set_graph": (ci, [vp, ci]),
         "fvhd_op_stem_conv": (ci, [vp, vp, ci, vp, vp, vp, ci, ci]),
         "fvhd_op_se_head": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
         "fvhd_op_ffn_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci]),
@@ -173,6 +174,10 @@ class Context:
     def set_attention_fp8(self, on: bool) -> None:
         """e4m3 MFMA operands in the MHSA core (BASELINE.json configs[4]); default off = bf16 operands."""
         check(load().fvhd_set_attention_fp8(self._h, int(bool(on))), "fvhd_set_attention_fp8")
+
+    def set_graph(self, on: bool) -> None:
+        """replay the interior steps as one hipGraph per batch size (launch-bound small batches)."""
+        check(load().fvhd_set_graph(self._h, int(bool(on))), "fvhd_set_graph")
 
     # ---- measurement ----
     def profile_enable(self, on: bool) -> None:

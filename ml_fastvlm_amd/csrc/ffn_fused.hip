@@ -184,12 +184,31 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
 #undef FFN_LD_ON
 }
 
+// Arrival counters, one per CU (index = XCC id, SE / SH / CU id from HW_ID): see "stagger" below.  Never reset: only the
+// parity of the arrival index is used, and every launch that staggers adds exactly two arrivals per CU.
+__device__ unsigned g_ffn_arrival[8 * 256];
+
 template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void ffn_fused_kernel(
     const bf16* __restrict__ A, const char* __restrict__ w1img, const char* __restrict__ w2img,
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ ls,
-    bf16* X, int M, int nwg)
+    bf16* X, int M, int nwg, int stagger)
 {
+    // Two workgroups per CU (OCC == 2) start together and, tile after tile, stay in phase: both stream their A / X tiles
+    // (HBM-bound, MFMA idle) and both run the chunk loop (MFMA-bound, HBM idle) at the same time - measured 26 % (C = 192)
+    // to 40 % (C = 96) of the kernel is that exposed memory phase.  The second workgroup to arrive on each CU in the first
+    // generation therefore starts `stagger` x ~4 us late (about half a tile); successors inherit the offset because a new
+    // workgroup is dispatched when its predecessor retires.  Only wave 0 sleeps: the others wait at the first barrier.
+    if constexpr (OCC == 2) {
+        if (stagger > 0 && blockIdx.x < 512 && threadIdx.x == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned k = atomicAdd(&g_ffn_arrival[((xcc & 7u) << 8) | ((hw >> 8) & 0xffu)], 1u);
+            if (k & 1u)
+                for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     constexpr int HID = 4 * C, KS = C / 16, NFR = C / 32, NCH = HID / 32;
     constexpr int CHB = 64 * C;             // bytes of one W1 (or W2) chunk image
     constexpr int NG = CHB / 1024;          // 1-KiB DMA pieces per chunk image
@@ -378,6 +397,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 static int g_ffn_lds_pad = 0;     // debug: extra dynamic LDS per workgroup (occupancy experiments, tools/bench_ops.py)
 extern "C" void fvhd_debug_set_ffn_lds_pad(int bytes) { g_ffn_lds_pad = bytes; }
 
+static int g_ffn_stagger[2] = {7, 2};     // C = 192, C = 96: first-generation start offset in s_sleep(127) units (~4 us)
+extern "C" void fvhd_debug_set_ffn_stagger(int c192, int c96) { g_ffn_stagger[0] = c192; g_ffn_stagger[1] = c96; }
+
 template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
 static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, const char* w2img, const float* b1,
                              const float* b2, const float* ls, bf16* X, int M)
@@ -393,7 +415,9 @@ static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, c
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = g_ffn_lds_pad + 1;
     }
-    hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
+    // stagger only when every CU gets its two workgroups and each runs several tiles' worth of successors
+    const int stagger = (OCC == 2 && nwg >= 4 * 512) ? g_ffn_stagger[C == 192 ? 0 : 1] : 0;
+    hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg, stagger);
     return hipGetLastError();
 }
 

@@ -143,6 +143,18 @@ struct fvhd_ctx {
     int attn_fp8 = 0;            // fvhd_set_attention_fp8 / FVHD_ATTN_FP8=1: e4m3 MFMA operands in MHSA (BASELINE.json configs[4])
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // hipGraph replay of the interior steps (fvhd_set_graph / FVHD_GRAPH=1): ~170 launches become one hipGraphLaunch.
+    // The stem (reads the caller's images) and the head (writes the caller's buffer) stay outside the graph, so a cached
+    // graph only holds library-owned pointers (workspace, packed weights) and is valid for any caller buffers.
+    struct GraphEntry {
+        int B, attn_fp8, dual, fused;
+        char* ws;
+        hipGraphExec_t exec;       // nullptr until the second call with this key (the first runs eagerly), or when capture failed
+        bool failed;
+        char *X0, *T0, *X1, *T1;   // activation ping-pong state after the interior steps
+    };
+    int graph = 0;
+    std::vector<GraphEntry> graphs;
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -274,9 +286,17 @@ Ws carve(const fvhd_ctx* c, char* base, int B, int hidden)
     return w;
 }
 
+void clear_graphs(fvhd_ctx* c)
+{
+    for (auto& g : c->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
 int ensure_ws(fvhd_ctx* c, int B)
 {
     if (c->ws && B <= c->ws_batch && c->hidden <= c->ws_hidden) return 0;
+    clear_graphs(c);                         // cached graphs point into the old arena
     const int nb = B > c->ws_batch ? B : c->ws_batch;
     const size_t need = carve(c, nullptr, nb, c->hidden).total;
     hipError_t e = hipDeviceSynchronize();   // growing the arena: make sure nothing still uses the old one
@@ -438,44 +458,101 @@ Ws sub_ws(const fvhd_ctx* c, const Ws& w, int b0)
 
 size_t dtype_size(int dt) { return dt == FVHD_F32 ? 4 : 2; }
 
+// Steps [first, last] for the whole batch on `st`, or - dualmode - as two independent halves on `st` and c->aux (forked
+// from and joined back into `st`).  (X0, T0) / (X1, T1): activation ping-pong buffers of the halves, updated in place.
+int run_range(fvhd_ctx* c, hipStream_t st, int first, int last, bool dualmode, const Ws& w, const Ws& w1, int B0, int B1,
+              char*& X0, char*& T0, char*& X1, char*& T1, const void* img0, const void* img1, int img_dtype,
+              void* out0, void* out1, int out_dtype)
+{
+    int e;
+    if (!dualmode) {
+        for (int i = first; i <= last; ++i)
+            if ((e = run_step(c, st, c->m.steps[i], w, X0, T0, B0, img0, img_dtype, out0, out_dtype))) return e;
+        return 0;
+    }
+    hipError_t he = hipEventRecord(c->ev_fork, st);
+    if (he == hipSuccess) he = hipStreamWaitEvent(c->aux, c->ev_fork, 0);
+    if (he != hipSuccess) return hip_fail("fork", he);
+    const int n = last - first + 1;
+    const int skew = c->dual >= 2 ? c->dual - 1 : 0;     // FVHD_DUAL=k+1: the second half is issued k steps behind the first
+    for (int i = 0; i < n + skew; ++i) {
+        if (i < n && (e = run_step(c, st, c->m.steps[first + i], w, X0, T0, B0, img0, img_dtype, out0, out_dtype))) return e;
+        const int j = i - skew;
+        if (j >= 0 && (e = run_step(c, c->aux, c->m.steps[first + j], w1, X1, T1, B1, img1, img_dtype, out1, out_dtype))) return e;
+    }
+    he = hipEventRecord(c->ev_join, c->aux);
+    if (he == hipSuccess) he = hipStreamWaitEvent(st, c->ev_join, 0);
+    if (he != hipSuccess) return hip_fail("join", he);
+    return 0;
+}
+
 int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out, int out_dtype, hipStream_t st)
 {
     if (img_dtype < 0 || img_dtype > 2 || out_dtype < 0 || out_dtype > 2) return fail("fvhd_encode: bad dtype");
     int e = prepare(c, B);
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
-    if (!c->dual || B < 2 || c->prof) {   // profiling brackets single launches with events: keep them on one stream, un-overlapped
-        char *X = w.X, *T = w.T;
-        for (const Step& sp : c->m.steps)
-            if ((e = run_step(c, st, sp, w, X, T, B, images, img_dtype, out, out_dtype))) return e;
-        return 0;
-    }
-    // ---- two halves on two streams ----
-    if (!c->aux) {
+    const int n = (int)c->m.steps.size();
+    // profiling brackets single launches with events: keep them on one stream, un-overlapped
+    const bool dualmode = c->dual && B >= 2 && !c->prof;
+    if (dualmode && !c->aux) {
         hipError_t he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
         if (he != hipSuccess) return hip_fail("aux stream/event creation", he);
     }
-    const int B0 = B / 2, B1 = B - B0;
+    const int B0 = dualmode ? B / 2 : B, B1 = B - B0;
     const size_t Tn = (size_t)(c->R / 64) * (c->R / 64);
     const Ws w1 = sub_ws(c, w, B0);
     const void* img1 = (const char*)images + (size_t)B0 * 3 * c->R * c->R * dtype_size(img_dtype);
     void* out1 = (char*)out + (size_t)B0 * Tn * kOutDim * dtype_size(out_dtype);
-    hipError_t he = hipEventRecord(c->ev_fork, st);
-    if (he == hipSuccess) he = hipStreamWaitEvent(c->aux, c->ev_fork, 0);
-    if (he != hipSuccess) return hip_fail("fork", he);
     char *X0 = w.X, *T0 = w.T, *X1 = w1.X, *T1 = w1.T;
-    const int n = (int)c->m.steps.size();
-    const int skew = c->dual >= 2 ? c->dual - 1 : 0;     // FVHD_DUAL=k+1: the second half is issued k steps behind the first
-    for (int i = 0; i < n + skew; ++i) {
-        if (i < n && (e = run_step(c, st, c->m.steps[i], w, X0, T0, B0, images, img_dtype, out, out_dtype))) return e;
-        const int j = i - skew;
-        if (j >= 0 && (e = run_step(c, c->aux, c->m.steps[j], w1, X1, T1, B1, img1, img_dtype, out1, out_dtype))) return e;
+
+    bool use_graph = c->graph && !c->prof && n >= 3;
+    if (use_graph) {                       // a caller that is itself capturing gets plain launches (they land in its graph)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_graph = false;
     }
-    he = hipEventRecord(c->ev_join, c->aux);
-    if (he == hipSuccess) he = hipStreamWaitEvent(st, c->ev_join, 0);
-    if (he != hipSuccess) return hip_fail("join", he);
+    if (!use_graph)
+        return run_range(c, st, 0, n - 1, dualmode, w, w1, B0, B1, X0, T0, X1, T1, images, img1, img_dtype, out, out1, out_dtype);
+
+    // ---- stem (whole batch: its output layout is the halves' layout) | graph of the interior steps | head per half ----
+    if ((e = run_step(c, st, c->m.steps[0], w, X0, T0, B, images, img_dtype, nullptr, 0))) return e;
+    fvhd_ctx::GraphEntry* g = nullptr;
+    for (auto& q : c->graphs)
+        if (q.B == B && q.attn_fp8 == c->attn_fp8 && q.dual == c->dual && q.fused == (int)c->use_fused_ffn && q.ws == c->ws) g = &q;
+    if (!g) {                              // first call with this key: eager (one-time kernel attributes are set on this pass)
+        if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
+        c->graphs.push_back({B, c->attn_fp8, c->dual, (int)c->use_fused_ffn, c->ws, nullptr, false, X0, T0, X1, T1});
+    } else if (g->failed) {
+        if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
+    } else {
+        if (!g->exec) {                    // second call: capture the same launch sequence instead of executing it
+            hipGraph_t graph = nullptr;
+            hipError_t he = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (he == hipSuccess) {
+                char *x0 = X0, *t0 = T0, *x1 = X1, *t1 = T1;
+                e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, x0, t0, x1, t1, nullptr, nullptr, 0, nullptr, nullptr, 0);
+                he = hipStreamEndCapture(st, &graph);
+                if (e == 0 && he == hipSuccess && graph) he = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+                else if (he == hipSuccess) he = hipErrorUnknown;
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (he != hipSuccess || !g->exec) {       // leave the stream usable and fall back to plain launches for this key
+                (void)hipGetLastError();
+                g->exec = nullptr;
+                g->failed = true;
+                if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
+            }
+        }
+        if (g->exec) {
+            hipError_t he = hipGraphLaunch(g->exec, st);
+            if (he != hipSuccess) return hip_fail("hipGraphLaunch", he);
+            X0 = g->X0; T0 = g->T0; X1 = g->X1; T1 = g->T1;
+        }
+    }
+    if ((e = run_step(c, st, c->m.steps[n - 1], w, X0, T0, B0, nullptr, 0, out, out_dtype))) return e;
+    if (dualmode && (e = run_step(c, st, c->m.steps[n - 1], w1, X1, T1, B1, nullptr, 0, out1, out_dtype))) return e;
     return 0;
 }
 
@@ -521,6 +598,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_DUAL")) c->dual = atoi(ev);
     if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_GRAPH")) c->graph = atoi(ev) != 0;
     *out = c;
     return 0;
 }
@@ -532,6 +610,7 @@ void fvhd_destroy(fvhd_ctx* c)
     (void)hipDeviceSynchronize();
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& ev : c->ev_pool) (void)hipEventDestroy(ev);
+    clear_graphs(c);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -624,6 +703,7 @@ int fvhd_finalize_weights(fvhd_ctx* c)
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return hip_fail("hipSetDevice", e);
     (void)hipDeviceSynchronize();
+    clear_graphs(c);                         // cached graphs point at the old packed weights
     if (c->wdev) (void)hipFree(c->wdev);
     c->wdev = nullptr;
     e = hipMalloc((void**)&c->wdev, pk.buf.size());
@@ -733,6 +813,13 @@ int fvhd_run_steps(fvhd_ctx* c, int first, int last, const void* x_in, int batch
 
 int fvhd_num_tokens(const fvhd_ctx* c) { return c ? (c->R / 64) * (c->R / 64) : 0; }
 int fvhd_hidden_size(const fvhd_ctx* c) { (void)c; return kOutDim; }
+
+int fvhd_set_graph(fvhd_ctx* c, int on)
+{
+    if (!c) return fail("fvhd_set_graph: ctx is NULL");
+    c->graph = on != 0;      // cached graphs stay valid (they are dropped when the workspace or the weights are replaced)
+    return 0;
+}
 
 int fvhd_set_attention_fp8(fvhd_ctx* c, int on)
 {

@@ -94,6 +94,8 @@ class MobileCLIPVisionTower(nn.Module):
         # MI355X-only option (no counterpart in the reference): e4m3 MFMA operands in the MHSA core, the "fp8 MFMA attention
         # path" of BASELINE.json configs[4]; read from the config object like the reference reads its own switches
         self.attention_fp8 = bool(getattr(args, "mm_vision_attention_fp8", False))
+        # ... and hipGraph replay of the tower's interior launches (include/fvhd.h: fvhd_set_graph), for launch-bound batches
+        self.hip_graph = bool(getattr(args, "mm_vision_hip_graph", False))
         self._ctx: Optional[_lib.Context] = None
         self._ctx_key = None
         self._dirty = True
@@ -162,6 +164,7 @@ class MobileCLIPVisionTower(nn.Module):
             self._ctx.finalize()
             self._dirty = False
         self._ctx.set_attention_fp8(self.attention_fp8)
+        self._ctx.set_graph(self.hip_graph)
         return self._ctx
 
     def sync_weights(self) -> None:

@@ -70,6 +70,31 @@ def bench_ffn(B=32, variants=True):
                 print(f"    NB={nb} waves={wv} variant {v:2d} pf={pf} ({names[v]:26s}): {tv*1e6:9.1f} us  {fl/tv/1e12:7.1f} TF/s")
 
 
+def bench_ffn_stagger(B=32):
+    """start offset of the second workgroup per CU (units of s_sleep 127 ~ 4 us): kernel time of the production launch"""
+    raw = C.CDLL(_lib.LIB_PATH)
+    for Cc, H in ((96, 256), (192, 128)):
+        M, HID = B * H * H, 4 * Cc
+        g = torch.Generator().manual_seed(0)
+        A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+        X = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+        W1 = (torch.randn(HID, Cc, generator=g) * Cc ** -0.5).to(torch.bfloat16).float().contiguous()
+        W2 = (torch.randn(Cc, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).float().contiguous()
+        nch, che = HID // 32, 32 * Cc
+        i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
+        i2 = torch.empty(nch * che, dtype=torch.bfloat16)
+        _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
+        i1, i2 = i1.to(DEV), i2.to(DEV)
+        b1 = torch.randn(HID, generator=g).to(DEV) * 0.1
+        b2 = torch.randn(Cc, generator=g).to(DEV) * 0.1
+        ls = torch.full((Cc,), 0.01, device=DEV)
+        for st in (0, 0, 1, 2, 3, 4, 5, 7, 9, 12, 16):
+            raw.fvhd_debug_set_ffn_stagger(st, st)
+            t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
+            print(f"ffn_fused C={Cc:4d} stagger {st:2d}: {t*1e6:9.1f} us  {16.0 * M * Cc * Cc / t / 1e12:7.1f} TF/s")
+    raw.fvhd_debug_set_ffn_stagger(7, 2)
+
+
 def bench_dw(B=32, modes=(0,)):
     raw = C.CDLL(_lib.LIB_PATH)
     for mode in modes:
@@ -237,4 +262,4 @@ def bench_overlap(B=16):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
+        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "ffn_stagger": bench_ffn_stagger, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
