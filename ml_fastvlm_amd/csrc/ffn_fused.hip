@@ -197,8 +197,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     // Two workgroups per CU (OCC == 2) start together and, tile after tile, stay in phase: both stream their A / X tiles
     // (HBM-bound, MFMA idle) and both run the chunk loop (MFMA-bound, HBM idle) at the same time - measured 26 % (C = 192)
     // to 40 % (C = 96) of the kernel is that exposed memory phase.  The second workgroup to arrive on each CU in the first
-    // generation therefore starts `stagger` x ~4 us late (about half a tile); successors inherit the offset because a new
-    // workgroup is dispatched when its predecessor retires.  Only wave 0 sleeps: the others wait at the first barrier.
+    // generation therefore starts `stagger` x ~4 us late; successors inherit the offset because a new workgroup is
+    // dispatched when its predecessor retires.  Only wave 0 sleeps: the others wait at the first barrier.  Measured gain:
+    // 3 % at C = 192, 1-2 % at C = 96, flat for offsets 1..12 - the pairs largely drift apart on their own.
     if constexpr (OCC == 2) {
         if (stagger > 0 && blockIdx.x < 512 && threadIdx.x == 0) {
             unsigned hw, xcc;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 static int g_ffn_lds_pad = 0;     // debug: extra dynamic LDS per workgroup (occupancy experiments, tools/bench_ops.py)
 extern "C" void fvhd_debug_set_ffn_lds_pad(int bytes) { g_ffn_lds_pad = bytes; }
 
-static int g_ffn_stagger[2] = {7, 2};     // C = 192, C = 96: first-generation start offset in s_sleep(127) units (~4 us)
+static int g_ffn_stagger[2] = {3, 3};     // C = 192, C = 96: first-generation start offset in s_sleep(127) units (~4 us); tools/bench_ops.py ffn_stagger
 extern "C" void fvhd_debug_set_ffn_stagger(int c192, int c96) { g_ffn_stagger[0] = c192; g_ffn_stagger[1] = c96; }
 
 template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>

@@ -92,7 +92,7 @@ def bench_ffn_stagger(B=32):
             raw.fvhd_debug_set_ffn_stagger(st, st)
             t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
             print(f"ffn_fused C={Cc:4d} stagger {st:2d}: {t*1e6:9.1f} us  {16.0 * M * Cc * Cc / t / 1e12:7.1f} TF/s")
-    raw.fvhd_debug_set_ffn_stagger(7, 2)
+    raw.fvhd_debug_set_ffn_stagger(3, 3)
 
 
 def bench_dw(B=32, modes=(0,)):
