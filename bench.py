@@ -229,14 +229,14 @@ def main():
         dt = t.item()
 
     result = {
-        "metric": "images/sec FastViTHD encode_images @1024x1024 bf16",
+        "metric": f"images/sec FastViTHD encode_images @{R}x{R} bf16",
         "value": round(world * B * args.steps / dt, 2),
         "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[1]: FastViTHD encoder{'' if args.tower_only else ' + mlp2x_gelu projector (H=%d)' % Hd}, "
+        "config": {"workload": f"BASELINE.json configs[{1 if R == 1024 else 4 if R == 1536 else '-'}]: FastViTHD encoder{'' if args.tower_only else ' + mlp2x_gelu projector (H=%d)' % Hd}, "
                                f"batch={B}/GPU synthetic {R}x{R} bf16 images in [0,1), seeded synthetic weights, "
                                f"{'tokens all-gathered over RCCL at the projector boundary' if world > 1 else 'single GPU'}",
                    "global_batch": B * world, "image_size": R, "tokens_per_image": (R // 64) ** 2, "parallelism": f"dp{world}",
