@@ -18,6 +18,7 @@ extern "C" {
 int fvhd_launch_dwconv(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
+int fvhd_launch_stem_fused(hipStream_t, const void*, int, void*, const float*, const float*, const float*, const float*, int, int);
 int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int, int);
 int fvhd_launch_stem_conv(hipStream_t, const void*, int, void*, const float*, const float*, int, int);
 int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, const float*, const float*, const float*,
@@ -136,6 +137,7 @@ struct fvhd_ctx {
     size_t ws_bytes = 0;
     int ws_batch = 0, ws_hidden = 0;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
+    bool use_fused_stem = false; // FVHD_FUSED_STEM=0: stem[0] and stem[1] as two launches through a [B,R/2,R/2,96] HBM tensor
     // The batch is encoded as two independent halves on two HIP streams (FVHD_DUAL=0 disables): images are independent
     // through the whole tower, and the MFMA-heavy ConvFFN kernels of one half co-run on the CUs with the VALU-bound
     // depthwise kernels / HBM-bound prologues of the other.  aux joins back into the caller's stream before returning.
@@ -382,6 +384,15 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
     int e;
     switch (sp.kind) {
     case S_STEM: {   // convolutional_stem (mci.py:553-603)
+        if (c->use_fused_stem) {
+            {
+                Scope s(c, st, C_STEM);
+                CHECK_LAUNCH(fvhd_launch_stem_fused(st, images, img_dtype, w.A, c->wp<float>(m.stem0_w), c->wp<float>(m.stem0_b),
+                                                    c->wp<float>(m.stem1.w), c->wp<float>(m.stem1.b), B, R),
+                             "fused stem launch");
+            }
+            return run_gemm(c, st, C_STEM, c->wdev, m.stem2, w.A, nullptr, nullptr, X, B * (R / 4) * (R / 4), FVHD_EPI_BIAS_GELU);
+        }
         {
             Scope s(c, st, C_STEM);
             CHECK_LAUNCH(fvhd_launch_stem_conv(st, images, img_dtype, w.H, c->wp<float>(m.stem0_w), c->wp<float>(m.stem0_b), B, R),
@@ -596,6 +607,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->R = image_size;
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_FUSED_STEM")) c->use_fused_stem = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_DUAL")) c->dual = atoi(ev);
     if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_GRAPH")) c->graph = atoi(ev) != 0;
@@ -908,6 +920,13 @@ int fvhd_op_stem_conv(fvhd_stream_t st, const void* img, int dtype, void* out, c
 {
     int e = fvhd_launch_stem_conv((hipStream_t)st, img, dtype, out, w, bias, B, R);
     return e ? hip_fail("fvhd_op_stem_conv", (hipError_t)e) : 0;
+}
+
+int fvhd_op_stem_fused(fvhd_stream_t st, const void* img, int dtype, void* out, const float* w0, const float* b0,
+                       const float* w1, const float* b1, int B, int R)
+{
+    int e = fvhd_launch_stem_fused((hipStream_t)st, img, dtype, out, w0, b0, w1, b1, B, R);
+    return e ? hip_fail("fvhd_op_stem_fused", (hipError_t)e) : 0;
 }
 
 int fvhd_op_se_head(fvhd_stream_t st, const void* y, float* pooled, float* scale, const float* wr, const float* br,

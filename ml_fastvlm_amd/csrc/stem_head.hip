@@ -127,6 +127,162 @@ extern "C" int fvhd_launch_stem_conv(hipStream_t st, const void* img, int dtype,
     return (int)hipGetLastError();
 }
 
+// ---- stem[0] + stem[1] fused: dense 3x3 s2 (3 -> 96) + GELU, then depthwise 3x3 s2 + GELU ---------
+// mci.py:563-586.  Unfused, stem[0] writes and stem[1] re-reads a [B, R/2, R/2, 96] bf16 tensor (1.6 GB at B = 32, R = 1024:
+// the two launches were write- / read-bound on it, 0.75 + 0.48 ms); here it only ever exists as LDS tiles.
+//   * a workgroup owns an 8 x 8 tile of stem[1] outputs = a 17 x 17 region of stem[0] outputs (recomputed halo: x1.13),
+//     computed exactly as stem_conv_kernel does (same MFMA shapes, k order, bias, GELU, bf16 rounding - the fused result
+//     is bit-identical to the two-kernel path) in 10 MFMA tiles of 32 positions, 2-3 per wave, and stored position-major
+//     [289][96] bf16 in LDS; positions outside the stem[0] map are stored as zeros (stem[1]'s zero padding);
+//   * then every thread computes 3 (pixel, 8-channel) units of the depthwise conv from LDS (taps fp32 in LDS, same
+//     accumulation order as dwconv_tiled_kernel) and stores 16 B, a pixel row of the tile being 1.5 KiB contiguous.
+#define STEMF_T 8                         // stem[1] outputs per tile side
+#define STEMF_R (2 * STEMF_T + 1)         // stem[0] region side (17)
+#define STEMF_NP (STEMF_R * STEMF_R)      // 289 positions
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ img, bf16* __restrict__ out,
+                                                         const float* __restrict__ w0, const float* __restrict__ b0,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         int B, int R)
+{
+    constexpr int CO = 96;
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    bf16x8* wimg = (bf16x8*)smem_f;                              // [cb][s][lane]: 6 KiB
+    float* lw1 = (float*)(smem_f + 6 * 64 * 16);                 // [9][96] fp32 taps of stem[1]
+    char* reg = smem_f + 6 * 64 * 16 + 9 * CO * 4;               // [289][96] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 31, half = lane >> 5;
+    auto tap_of = [](int h, int q) { const int row = (h ? 5 : 0) + q / 3; return (q < (h ? 12 : 15)) ? row * 3 + q % 3 : -1; };
+    for (int i = tid; i < 6 * 64; i += 256) {
+        const int l = i & 63, s = (i >> 6) & 1, cb = i >> 7;
+        const int ch = cb * 32 + (l & 31), h = l >> 5;
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = tap_of(h, s * 8 + j);
+            f[j] = (bf16)(t >= 0 ? w0[t * CO + ch] : 0.0f);
+        }
+        wimg[i] = f;
+    }
+    for (int i = tid; i < 9 * CO / 4; i += 256) *(f32x4*)&lw1[i * 4] = *(const f32x4*)&w1[i * 4];
+    __syncthreads();
+    bf16x8 wa[3][2];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wa[cb][s] = wimg[(cb * 2 + s) * 64 + lane];
+    f32x4 bv[3][4];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[cb][q] = *(const f32x4*)(b0 + cb * 32 + q * 8 + half * 4);
+
+    const int H1 = R / 2, H2 = R / 4, TXY = H2 / STEMF_T;        // stem[0] map side, stem[1] map side, tiles per side
+    const int tile = blockIdx.x;
+    const int tx = tile % TXY, ty = (tile / TXY) % TXY, b = tile / (TXY * TXY);
+    const int cy0 = 2 * ty * STEMF_T - 1, cx0 = 2 * tx * STEMF_T - 1;          // stem[0] coordinates of region position (0, 0)
+
+    // ---- phase 1: the stem[0] region, 32 positions per MFMA tile
+    for (int t = wave; t * 32 < STEMF_NP; t += 4) {
+        const int p = t * 32 + px;
+        const int ry = p / STEMF_R, rx = p - ry * STEMF_R;
+        const int gy = cy0 + ry, gx = cx0 + rx;                   // this lane's stem[0] output pixel
+        const bool inside = p < STEMF_NP && gy >= 0 && gy < H1 && gx >= 0 && gx < H1;
+        bf16x8 xb[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int tp = tap_of(half, q);
+            float v = 0.0f;
+            const int row = (half ? 5 : 0) + q / 3, kx = q % 3;
+            const int ci = row / 3, ky = row % 3;
+            const int iy = gy * 2 + ky - 1, ix = gx * 2 + kx - 1;
+            if (inside && tp >= 0 && iy >= 0 && iy < R && ix >= 0 && ix < R)
+                v = ld_as_f32<T>(img, (((size_t)b * 3 + ci) * R + iy) * R + ix);
+            xb[q >> 3][q & 7] = (bf16)v;
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cb][0], xb[0], z, 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cb][1], xb[1], acc[cb], 0, 0, 0);
+        }
+        if (p < STEMF_NP) {
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = inside ? gelu_erf(acc[cb][4 * q + j] + bv[cb][q][j]) : 0.0f;
+                    *(bf16x4*)(reg + p * (CO * 2) + (cb * 32 + q * 8 + half * 4) * 2) = f32_to_bf4(g);
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: stem[1] on the LDS region; unit u = (pixel, 8-channel group), 768 units, 3 per thread
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int u = i * 256 + tid;
+        const int cg = u % 12, pxl = u / 12;
+        const int oy = pxl / STEMF_T, ox = pxl - oy * STEMF_T;
+        float acc[8];
+        {
+            const f32x4 c0 = *(const f32x4*)(b1 + cg * 8), c1 = *(const f32x4*)(b1 + cg * 8 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { acc[c] = c0[c]; acc[4 + c] = c1[c]; }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x8 v = bf8_to_f32(*(const bf16x8*)(reg + ((2 * oy + ky) * STEMF_R + 2 * ox + kx) * (CO * 2) + cg * 16));
+                const f32x4 t0 = *(const f32x4*)&lw1[(ky * 3 + kx) * CO + cg * 8], t1 = *(const f32x4*)&lw1[(ky * 3 + kx) * CO + cg * 8 + 4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[c] = __builtin_fmaf(t0[c], v[c], acc[c]);
+                    acc[4 + c] = __builtin_fmaf(t1[c], v[4 + c], acc[4 + c]);
+                }
+            }
+        f32x8 r;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) r[c] = gelu_erf(acc[c]);
+        *(bf16x8*)(out + (((size_t)b * H2 + ty * STEMF_T + oy) * H2 + tx * STEMF_T + ox) * CO + cg * 8) = f32_to_bf8(r);
+    }
+}
+
+// img [B,3,R,R] (dtype) -> out [B,R/4,R/4,96] bf16 = gelu(dw3x3s2(gelu(conv3x3s2(img) + b0)) + b1);  R % 64 == 0
+extern "C" int fvhd_launch_stem_fused(hipStream_t st, const void* img, int dtype, void* out, const float* w0, const float* b0,
+                                      const float* w1, const float* b1, int B, int R)
+{
+    if (R % 64) return (int)hipErrorInvalidValue;
+    const int txy = R / 4 / STEMF_T;
+    const size_t shmem = 6 * 64 * 16 + 9 * 96 * 4 + (size_t)STEMF_NP * 96 * 2;
+    dim3 grid((unsigned)((size_t)B * txy * txy)), block(256);
+    static bool attr_set[64][3];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#define STEMF_LAUNCH(TT, IDX)                                                                                                  \
+    do {                                                                                                                       \
+        if (!attr_set[dev & 63][IDX]) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute((const void*)stem_fused_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)shmem);                                                                    \
+            if (e != hipSuccess) return (int)e;                                                                                \
+            attr_set[dev & 63][IDX] = true;                                                                                    \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(stem_fused_kernel<TT>, grid, block, shmem, st, (const TT*)img, (bf16*)out, w0, b0, w1, b1, B, R);    \
+    } while (0)
+    if (dtype == FVHD_F32) STEMF_LAUNCH(float, 0);
+    else if (dtype == FVHD_F16) STEMF_LAUNCH(_Float16, 1);
+    else if (dtype == FVHD_BF16) STEMF_LAUNCH(bf16, 2);
+    else return (int)hipErrorInvalidValue;
+#undef STEMF_LAUNCH
+    return (int)hipGetLastError();
+}
+
 // ---- SE: global average pool over the T tokens of each image -------------------------------------
 // y [B, T, C] bf16 -> pooled [B, C] fp32.  grid (C/256, B), one thread per channel.
 __global__ __launch_bounds__(256) void se_pool_kernel(const bf16* __restrict__ y, float* __restrict__ pooled, int T, int C)

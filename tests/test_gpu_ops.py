@@ -383,6 +383,31 @@ def test_stem_conv_tap_order():
     _close(out.permute(0, 3, 1, 2), want, rtol=8e-3, atol_rms=4e-3, what="stem conv one-hot taps")
 
 
+@pytest.mark.parametrize("dtype,B,R", [(torch.bfloat16, 2, 64), (torch.float32, 1, 128), (torch.float16, 3, 192)])
+def test_stem_fused_equals_two_kernels(dtype, B, R):
+    """stem[0] + stem[1] in one launch: bit-identical to fvhd_op_stem_conv followed by the stride-2 depthwise kernel (same
+    MFMA shapes, accumulation orders and rounding points), and within tolerance of the fp32 reference of both modules."""
+    lib = _lib.load()
+    img = torch.rand(B, 3, R, R, generator=torch.Generator().manual_seed(0)).to(dtype)
+    w0, b0 = _rand(96, 3, 3, 3, seed=1, scale=0.5), _rand(96, seed=2, scale=0.1)
+    w1, b1 = _rand(96, 1, 3, 3, seed=3, scale=0.4), _rand(96, seed=4, scale=0.1)
+    w0d = w0.reshape(96, 27).t().contiguous().to(DEV)
+    w1d = w1.reshape(96, 9).t().contiguous().to(DEV)
+    imd, b0d, b1d = img.to(DEV), b0.to(DEV), b1.to(DEV)
+    mid = torch.empty(B, R // 2, R // 2, 96, dtype=torch.bfloat16, device=DEV)
+    two = torch.empty(B, R // 4, R // 4, 96, dtype=torch.bfloat16, device=DEV)
+    one = torch.full_like(two, 7.0)
+    _lib.check(lib.fvhd_op_stem_conv(_stream(), _p(imd), _lib.dtype_code(dtype), _p(mid), _p(w0d), _p(b0d), B, R), "stem conv")
+    _lib.check(lib.fvhd_op_dwconv(_stream(), _p(mid), _p(two), _p(w1d), _p(b1d), B, R // 2, R // 2, 96, 3, 2, 1, 1), "stem dw")
+    _lib.check(lib.fvhd_op_stem_fused(_stream(), _p(imd), _lib.dtype_code(dtype), _p(one), _p(w0d), _p(b0d), _p(w1d), _p(b1d), B, R),
+               "stem fused")
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), f"fused stem differs from the two-kernel path: {(one.float() - two.float()).abs().max().item()}"
+    y0 = _bf(O.gelu(F.conv2d(_bf(img).float(), _bf(w0).float(), b0, stride=2, padding=1))).float()
+    want = O.gelu(F.conv2d(y0, w1, b1, stride=2, padding=1, groups=96))
+    _close(one.permute(0, 3, 1, 2), want, what=f"fused stem {dtype} B{B} R{R}")
+
+
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_se_head(out_dtype):
     lib = _lib.load()

@@ -70,6 +70,19 @@ def bench_ffn(B=32, variants=True):
                 print(f"    NB={nb} waves={wv} variant {v:2d} pf={pf} ({names[v]:26s}): {tv*1e6:9.1f} us  {fl/tv/1e12:7.1f} TF/s")
 
 
+def bench_stem(B=32, R=1024):
+    img = torch.rand(B, 3, R, R).to(DEV, torch.bfloat16)
+    w0, b0 = (torch.randn(27, 96) * 0.3).to(DEV), (torch.randn(96) * 0.1).to(DEV)
+    w1, b1 = (torch.randn(9, 96) * 0.3).to(DEV), (torch.randn(96) * 0.1).to(DEV)
+    mid = torch.empty(B, R // 2, R // 2, 96, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(B, R // 4, R // 4, 96, dtype=torch.bfloat16, device=DEV)
+    t0 = timeit(lambda: _lib.check(lib.fvhd_op_stem_conv(stream(), p(img), 2, p(mid), p(w0), p(b0), B, R)))
+    t1 = timeit(lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(mid), p(out), p(w1), p(b1), B, R // 2, R // 2, 96, 3, 2, 1, 1)))
+    t2 = timeit(lambda: _lib.check(lib.fvhd_op_stem_fused(stream(), p(img), 2, p(out), p(w0), p(b0), p(w1), p(b1), B, R)))
+    by = 2.0 * (img.numel() + out.numel())
+    print(f"stem[0] {t0*1e6:8.1f} us + stem[1] {t1*1e6:8.1f} us = {(t0+t1)*1e6:8.1f} us;  fused {t2*1e6:8.1f} us ({by/t2/1e9:6.1f} GB/s algorithmic)")
+
+
 def bench_ffn_stagger(B=32):
     """start offset of the second workgroup per CU (units of s_sleep 127 ~ 4 us): kernel time of the production launch"""
     raw = C.CDLL(_lib.LIB_PATH)
@@ -262,4 +275,4 @@ def bench_overlap(B=16):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "ffn_stagger": bench_ffn_stagger, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
+        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "ffn_stagger": bench_ffn_stagger, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
