@@ -137,7 +137,7 @@ struct fvhd_ctx {
     size_t ws_bytes = 0;
     int ws_batch = 0, ws_hidden = 0;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
-    bool use_fused_stem = false; // FVHD_FUSED_STEM=0: stem[0] and stem[1] as two launches through a [B,R/2,R/2,96] HBM tensor
+    bool use_fused_stem = true;  // FVHD_FUSED_STEM=0: stem[0] and stem[1] as two launches through a [B,R/2,R/2,96] HBM tensor
     // The batch is encoded as two independent halves on two HIP streams (FVHD_DUAL=0 disables): images are independent
     // through the whole tower, and the MFMA-heavy ConvFFN kernels of one half co-run on the CUs with the VALU-bound
     // depthwise kernels / HBM-bound prologues of the other.  aux joins back into the caller's stream before returning.

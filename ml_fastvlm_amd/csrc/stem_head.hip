@@ -139,6 +139,11 @@ extern "C" int fvhd_launch_stem_conv(hipStream_t st, const void* img, int dtype,
 #define STEMF_T 8                         // stem[1] outputs per tile side
 #define STEMF_R (2 * STEMF_T + 1)         // stem[0] region side (17)
 #define STEMF_NP (STEMF_R * STEMF_R)      // 289 positions
+#define STEMF_IR (2 * STEMF_R + 1)        // image rows / columns under the region (35)
+#define STEMF_IS 40                       // image tile row stride in LDS (elements): 4-B aligned 3-pixel runs
+#define STEMF_IB (3 * STEMF_IR * STEMF_IS * 2)   // image tile bytes (8400)
+#define STEMF_PS 208                      // bytes per region position in LDS: 96 bf16 + 16 B pad (a 192-B stride put the 16
+                                          // lanes of a ds_write_b64 group on 4 banks: 8-way conflicts; 208 leaves 2-way)
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ img, bf16* __restrict__ out,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
@@ -149,7 +154,8 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     bf16x8* wimg = (bf16x8*)smem_f;                              // [cb][s][lane]: 6 KiB
     float* lw1 = (float*)(smem_f + 6 * 64 * 16);                 // [9][96] fp32 taps of stem[1]
-    char* reg = smem_f + 6 * 64 * 16 + 9 * CO * 4;               // [289][96] bf16
+    bf16* itile = (bf16*)(smem_f + 6 * 64 * 16 + 9 * CO * 4);    // image tile [3][35][STEMF_IS] bf16 (zero outside the image)
+    char* reg = smem_f + 6 * 64 * 16 + 9 * CO * 4 + STEMF_IB;    // [289][96] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = lane & 31, half = lane >> 5;
     auto tap_of = [](int h, int q) { const int row = (h ? 5 : 0) + q / 3; return (q < (h ? 12 : 15)) ? row * 3 + q % 3 : -1; };
@@ -165,6 +171,37 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
         wimg[i] = f;
     }
     for (int i = tid; i < 9 * CO / 4; i += 256) *(f32x4*)&lw1[i * 4] = *(const f32x4*)&w1[i * 4];
+
+    const int H1 = R / 2, H2 = R / 4, TXY = H2 / STEMF_T;        // stem[0] map side, stem[1] map side, tiles per side
+    const int tile = blockIdx.x;
+    const int tx = tile % TXY, ty = (tile / TXY) % TXY, b = tile / (TXY * TXY);
+    const int cy0 = 2 * ty * STEMF_T - 1, cx0 = 2 * tx * STEMF_T - 1;          // stem[0] coordinates of region position (0, 0)
+
+    // ---- phase 0: the 3 x 35 x 35 image pixels under the region, rounded to bf16 (the tower's compute dtype), zero outside
+    //      the image, into LDS: the im2col gather below is then two aligned ds_read_b32 per (channel, tap row) instead of
+    //      three bounds-checked 2-byte global loads with 64-bit addressing
+    {
+        const int iy0 = 2 * cy0 - 1, ix0 = 2 * cx0 - 1;
+        const T* ib = img + (size_t)b * 3 * R * R;
+        constexpr int NE = 3 * STEMF_IR * STEMF_IR, NIT = (NE + 255) / 256;     // 3675 elements, 15 per thread
+        float v[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {                           // all loads in flight before the first LDS write
+            const int e = i * 256 + tid;
+            const int row = e / STEMF_IR, col = e - row * STEMF_IR;
+            const int ci = row / STEMF_IR, r = row - ci * STEMF_IR;
+            const int iy = iy0 + r, ix = ix0 + col;
+            const bool ok = e < NE && iy >= 0 && iy < R && ix >= 0 && ix < R;
+            const float ld = ld_as_f32<T>(ib, ok ? (unsigned)((ci * R + iy) * R + ix) : 0u);
+            v[i] = ok ? ld : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = i * 256 + tid;
+            const int row = e / STEMF_IR, col = e - row * STEMF_IR;
+            if (e < NE) itile[row * STEMF_IS + col] = (bf16)v[i];
+        }
+    }
     __syncthreads();
     bf16x8 wa[3][2];
 #pragma unroll
@@ -177,29 +214,34 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[cb][q] = *(const f32x4*)(b0 + cb * 32 + q * 8 + half * 4);
 
-    const int H1 = R / 2, H2 = R / 4, TXY = H2 / STEMF_T;        // stem[0] map side, stem[1] map side, tiles per side
-    const int tile = blockIdx.x;
-    const int tx = tile % TXY, ty = (tile / TXY) % TXY, b = tile / (TXY * TXY);
-    const int cy0 = 2 * ty * STEMF_T - 1, cx0 = 2 * tx * STEMF_T - 1;          // stem[0] coordinates of region position (0, 0)
-
     // ---- phase 1: the stem[0] region, 32 positions per MFMA tile
     for (int t = wave; t * 32 < STEMF_NP; t += 4) {
         const int p = t * 32 + px;
         const int ry = p / STEMF_R, rx = p - ry * STEMF_R;
         const int gy = cy0 + ry, gx = cx0 + rx;                   // this lane's stem[0] output pixel
         const bool inside = p < STEMF_NP && gy >= 0 && gy < H1 && gx >= 0 && gx < H1;
-        bf16x8 xb[2];
+        // k-slot q = 3 i + kx of this lane's k-half <-> tap row (ci, ky) = 5 half + i, pixel 2 rx + kx of image-tile row
+        // ci * 35 + 2 ry + ky: per tap row two words wa = (px0, px1), wb = (px2, -).  (half 1 has 4 rows: its fifth read
+        // and, for lanes past position 288, rows past the tile land in the LDS that follows - never used.)
+        unsigned ra[5], rb2[5];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int tp = tap_of(half, q);
-            float v = 0.0f;
-            const int row = (half ? 5 : 0) + q / 3, kx = q % 3;
-            const int ci = row / 3, ky = row % 3;
-            const int iy = gy * 2 + ky - 1, ix = gx * 2 + kx - 1;
-            if (inside && tp >= 0 && iy >= 0 && iy < R && ix >= 0 && ix < R)
-                v = ld_as_f32<T>(img, (((size_t)b * 3 + ci) * R + iy) * R + ix);
-            xb[q >> 3][q & 7] = (bf16)v;
+        for (int i = 0; i < 5; ++i) {
+            const int rr = half * 5 + i;                          // 0..8 (9 = unused)
+            const int ci = rr / 3, ky = rr - ci * 3;
+            const unsigned* src = (const unsigned*)(itile + (ci * STEMF_IR + 2 * ry + ky) * STEMF_IS + 2 * rx);
+            ra[i] = src[0];
+            rb2[i] = src[1];
         }
+        u32x4 x0, x1;
+        x0[0] = ra[0];
+        x0[1] = (rb2[0] & 0xffffu) | (ra[1] << 16);
+        x0[2] = (ra[1] >> 16) | (rb2[1] << 16);
+        x0[3] = ra[2];
+        x1[0] = (rb2[2] & 0xffffu) | (ra[3] << 16);
+        x1[1] = (ra[3] >> 16) | (rb2[3] << 16);
+        x1[2] = half ? 0u : ra[4];
+        x1[3] = half ? 0u : (rb2[4] & 0xffffu);
+        bf16x8 xb[2] = {__builtin_bit_cast(bf16x8, x0), __builtin_bit_cast(bf16x8, x1)};
         f32x16 acc[3];
 #pragma unroll
         for (int cb = 0; cb < 3; ++cb) {
@@ -217,7 +259,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
                     f32x4 g;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = inside ? gelu_erf(acc[cb][4 * q + j] + bv[cb][q][j]) : 0.0f;
-                    *(bf16x4*)(reg + p * (CO * 2) + (cb * 32 + q * 8 + half * 4) * 2) = f32_to_bf4(g);
+                    *(bf16x4*)(reg + p * STEMF_PS + (cb * 32 + q * 8 + half * 4) * 2) = f32_to_bf4(g);
                 }
         }
     }
@@ -239,7 +281,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const f32x8 v = bf8_to_f32(*(const bf16x8*)(reg + ((2 * oy + ky) * STEMF_R + 2 * ox + kx) * (CO * 2) + cg * 16));
+                const f32x8 v = bf8_to_f32(*(const bf16x8*)(reg + ((2 * oy + ky) * STEMF_R + 2 * ox + kx) * STEMF_PS + cg * 16));
                 const f32x4 t0 = *(const f32x4*)&lw1[(ky * 3 + kx) * CO + cg * 8], t1 = *(const f32x4*)&lw1[(ky * 3 + kx) * CO + cg * 8 + 4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -260,7 +302,7 @@ extern "C" int fvhd_launch_stem_fused(hipStream_t st, const void* img, int dtype
 {
     if (R % 64) return (int)hipErrorInvalidValue;
     const int txy = R / 4 / STEMF_T;
-    const size_t shmem = 6 * 64 * 16 + 9 * 96 * 4 + (size_t)STEMF_NP * 96 * 2;
+    const size_t shmem = 6 * 64 * 16 + 9 * 96 * 4 + STEMF_IB + (size_t)STEMF_NP * STEMF_PS;
     dim3 grid((unsigned)((size_t)B * txy * txy)), block(256);
     static bool attr_set[64][3];
     int dev = 0;

@@ -405,7 +405,8 @@ def test_stem_fused_equals_two_kernels(dtype, B, R):
     assert torch.equal(one, two), f"fused stem differs from the two-kernel path: {(one.float() - two.float()).abs().max().item()}"
     y0 = _bf(O.gelu(F.conv2d(_bf(img).float(), _bf(w0).float(), b0, stride=2, padding=1))).float()
     want = O.gelu(F.conv2d(y0, w1, b1, stride=2, padding=1, groups=96))
-    _close(one.permute(0, 3, 1, 2), want, what=f"fused stem {dtype} B{B} R{R}")
+    # two chained modules: a 1-ulp flip of the bf16 intermediate (0.4 %) times a tap of ~0.4 adds to the single-op budget
+    _close(one.permute(0, 3, 1, 2), want, rtol=2e-2, atol_rms=2e-2, what=f"fused stem {dtype} B{B} R{R}")
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
