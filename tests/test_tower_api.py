@@ -44,6 +44,16 @@ def test_delay_load_with_unfreeze_loads_eagerly():
     assert t.is_loaded and t.tune_vision_tower
 
 
+def test_mi355x_options_default_off_and_read_from_args():
+    """The two options that have no counterpart in the reference are opt-in, so a reference config object
+    that knows nothing about them builds the parity path."""
+    t = fv.MobileCLIPVisionTower("mobileclip_l_256", ARGS, delay_load=True)
+    assert t.attention_fp8 is False and t.hip_graph is False
+    t = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_attention_fp8=True,
+                                                                    mm_vision_hip_graph=1), delay_load=True)
+    assert t.attention_fp8 is True and t.hip_graph is True
+
+
 def test_unknown_names_raise_value_error():
     with pytest.raises(ValueError, match="Unsupported model name"):
         fv.MobileCLIPVisionTower("fooclip_x_1024", ARGS)
