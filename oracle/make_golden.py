@@ -14,7 +14,10 @@ in fp32 on seeded inputs and stores:
                            every network entry's output (stem, 11 entries, conv_exp);
 * `tower_r1024_b1.npz`   - every 8th token of the `[1,256,3072]` output at 1024x1024 plus
                            whole-tensor statistics;
-* `projector_h896.npz`   - `mlp2x_gelu` projector output for 32 tokens, H=896 (FastVLM-0.5B).
+* `projector_h896.npz`   - `mlp2x_gelu` projector output for 32 tokens, H=896 (FastVLM-0.5B);
+* `tower_r1536_b1.npz`   - (`--extra`) every 16th token of the `[1,576,3072]` output at 1536x1536 (BASELINE.json configs[4]
+                           geometry) plus statistics and the reference's own bf16 error there;
+* `projector_h3584.npz`  - (`--extra`) projector output for 32 tokens, H=3584 (FastVLM-7B, configs[3]).
 
 The fixtures are what pins `oracle/fastvithd_oracle.py` on machines where the reference
 tree is absent (the GPU box).
@@ -138,5 +141,34 @@ def main():
     print("projector out", tuple(y.shape), "absmax %.3f" % y.abs().max())
 
 
+def extra():
+    """Fixtures for the other BASELINE.json configurations; leaves the files written by main() untouched."""
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_flush_denormal(True)
+    tower = ref_import.build_reference_tower(1536)
+    _load_synth(tower)
+    images = synth.synthetic_images(1, 1536, seed=21)
+    t0 = time.time()
+    out = tower(images)
+    print("reference 1536^2 fp32 B=1: %.2f s" % (time.time() - t0))
+    assert out.shape == (1, 576, 3072)
+    bf = _reference_bf16_error(tower, images, out, "1536")
+    np.savez_compressed(
+        os.path.join(GOLD, "tower_r1536_b1.npz"), **bf,
+        out_tok16=out[:, ::16].numpy().copy(), weight_seed=np.int64(WEIGHT_SEED), image_seed=np.int64(21),
+        l2=np.float64(out.double().pow(2).sum().sqrt()), absmax=np.float64(out.abs().max()),
+        token_l2=out.double().pow(2).sum(-1).sqrt().numpy()[0])
+    proj = ref_import.build_reference_projector(3584)
+    pj = synth.synthetic_projector_state_dict(3584, WEIGHT_SEED)
+    proj.load_state_dict(pj, strict=True)
+    tok = out[:, :32].contiguous()
+    with torch.no_grad():
+        y = proj(tok)
+    np.savez_compressed(os.path.join(GOLD, "projector_h3584.npz"), tokens=tok.numpy(), out=y.numpy(),
+                        weight_seed=np.int64(WEIGHT_SEED))
+    print("projector H=3584 out", tuple(y.shape), "absmax %.3f" % y.abs().max())
+
+
 if __name__ == "__main__":
-    main()
+    extra() if "--extra" in sys.argv else main()
