@@ -210,6 +210,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
                 for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
         }
     }
+    // One workgroup per CU (OCC == 1, C = 384): every CU streams its tile in at the same moment and HBM idles while all of
+    // them run the chunk loop.  Experimental (default off, fvhd_debug_set_ffn_stagger384): the odd-numbered CUs start
+    // `stagger` x ~4 us late so that the two halves of the chip alternate between memory phase and chunk loop.
+    if constexpr (OCC == 1) {
+        if (stagger > 0 && blockIdx.x < 256 && threadIdx.x == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            if ((hw >> 8) & 1u)
+                for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     constexpr int HID = 4 * C, KS = C / 16, NFR = C / 32, NCH = HID / 32;
     constexpr int CHB = 64 * C;             // bytes of one W1 (or W2) chunk image
     constexpr int NG = CHB / 1024;          // 1-KiB DMA pieces per chunk image
@@ -398,6 +409,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 static int g_ffn_lds_pad = 0;     // debug: extra dynamic LDS per workgroup (occupancy experiments, tools/bench_ops.py)
 extern "C" void fvhd_debug_set_ffn_lds_pad(int bytes) { g_ffn_lds_pad = bytes; }
 
+static int g_ffn_stagger384 = 0;          // C = 384 (one workgroup per CU): start offset of the odd CUs, same units; experimental
+extern "C" void fvhd_debug_set_ffn_stagger384(int v) { g_ffn_stagger384 = v; }
 static int g_ffn_stagger[2] = {3, 3};     // C = 192, C = 96: first-generation start offset in s_sleep(127) units (~4 us); tools/bench_ops.py ffn_stagger
 extern "C" void fvhd_debug_set_ffn_stagger(int c192, int c96) { g_ffn_stagger[0] = c192; g_ffn_stagger[1] = c96; }
 
@@ -417,7 +430,7 @@ static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, c
         attr_set[dev & 63] = g_ffn_lds_pad + 1;
     }
     // stagger only when every CU gets its two workgroups and each runs several tiles' worth of successors
-    const int stagger = (OCC == 2 && nwg >= 4 * 512) ? g_ffn_stagger[C == 192 ? 0 : 1] : 0;
+    const int stagger = (OCC == 2 && nwg >= 4 * 512) ? g_ffn_stagger[C == 192 ? 0 : 1] : (OCC == 1 && nwg >= 3 * 256) ? g_ffn_stagger384 : 0;
     hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg, stagger);
     return hipGetLastError();
 }

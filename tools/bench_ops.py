@@ -86,7 +86,7 @@ def bench_stem(B=32, R=1024):
 def bench_ffn_stagger(B=32):
     """start offset of the second workgroup per CU (units of s_sleep 127 ~ 4 us): kernel time of the production launch"""
     raw = C.CDLL(_lib.LIB_PATH)
-    for Cc, H in ((96, 256), (192, 128)):
+    for Cc, H in ((384, 64), (96, 256), (192, 128)) if len(sys.argv) > 2 and sys.argv[2] == "all" else ((384, 64),):
         M, HID = B * H * H, 4 * Cc
         g = torch.Generator().manual_seed(0)
         A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
@@ -103,9 +103,11 @@ def bench_ffn_stagger(B=32):
         ls = torch.full((Cc,), 0.01, device=DEV)
         for st in (0, 0, 1, 2, 3, 4, 5, 7, 9, 12, 16):
             raw.fvhd_debug_set_ffn_stagger(st, st)
+            raw.fvhd_debug_set_ffn_stagger384(st)
             t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
             print(f"ffn_fused C={Cc:4d} stagger {st:2d}: {t*1e6:9.1f} us  {16.0 * M * Cc * Cc / t / 1e12:7.1f} TF/s")
     raw.fvhd_debug_set_ffn_stagger(3, 3)
+    raw.fvhd_debug_set_ffn_stagger384(0)
 
 
 def bench_dw(B=32, modes=(0,)):
@@ -273,6 +275,6 @@ def bench_overlap(B=16):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ffn", "dw", "gemm", "attn"]
+    which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
         {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "ffn_stagger": bench_ffn_stagger, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
