@@ -8,7 +8,8 @@ import os
 from typing import Dict, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfvhd.so")
+# FVHD_LIB: another build of the same ABI (the ablation library of `python -m ml_fastvlm_amd.build` with FVHD_FFN_ABLATE=1)
+LIB_PATH = os.environ.get("FVHD_LIB") or os.path.join(_HERE, "libfvhd.so")
 
 F32, F16, BF16 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RESID = 0, 1, 2, 3

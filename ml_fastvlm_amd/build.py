@@ -44,8 +44,12 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(BUILD, exist_ok=True)
+def build_library(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+    """ablate=True (or FVHD_FFN_ABLATE=1 on the command line): the experiment library `libfvhd_ablate.so` with the fused-FFN
+    ablation variants compiled in (tools/bench_ops.py picks it with FVHD_LIB); never what the package loads by default."""
+    build_dir = BUILD + ("_ablate" if ablate else "")
+    lib = LIB.replace("libfvhd.so", "libfvhd_ablate.so") if ablate else LIB
+    os.makedirs(build_dir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(PKG), "include", "fvhd.h"))
@@ -54,10 +58,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        o = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
+            extra = EXTRA_FLAGS.get(src, []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
+            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -71,10 +76,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         for warn in ex.map(run, jobs):
             if verbose and warn:
                 print(warn, file=sys.stderr)
-    if force or jobs or _newer(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _newer(lib, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, ablate=os.environ.get("FVHD_FFN_ABLATE") == "1"))

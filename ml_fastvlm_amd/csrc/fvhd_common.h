@@ -28,30 +28,26 @@ FVHD_DEV bf16x4 f32_to_bf4(f32x4 v) { return __builtin_convertvector(v, bf16x4);
 
 // ---- erf GELU -------------------------------------------------------------------------------------
 // gelu(x) = x * Phi(x) - the *erf* GELU the reference uses (nn.GELU() default, mci.py:108/387/870), not the tanh form.
-//   Phi(x) = 0.5 + xc * Q(xc^2),  xc = clamp(x, -4, 4),  Q = degree-9 polynomial (least-squares fit on Chebyshev nodes of
-//   u = x^2 in [0, 16]); |Phi error| <= 6.2e-6 in fp32 Horner form on [-4, 4] (fit 1.7e-6 + cancellation), i.e.
-//   |gelu error| <= 6.2e-6 |x|: <= 1/8 of a bf16 half-ulp wherever gelu(x) is not itself below 1e-3.  Outside the clamp
-//   Phi saturates at Phi(+-4) = 1 - 3.2e-5 / 3.2e-5 (gelu(-8) = -2.5e-4 instead of 0).
-// Why not A&S 7.1.26 (round 1, 1.5e-7): that form needs v_rcp + v_exp (quarter rate, 8 cycles each) and half-rate
-// abs/max fix-ups - ~50 VALU cycles per wave64 value; this one is 12 full-rate FMA/MUL + one v_med3 (~30 cycles) and
-// packs two values per v_pk_fma_f32, halving the issue slots it takes from the MFMA stream in the fused ConvFFN kernel.
-// Every activation it feeds is rounded to bf16 (relative 2e-3 half-ulp) right after.
-#define FVHD_GELU_C0 3.989380888e-01f
-#define FVHD_GELU_C1 -6.647037283e-02f
-#define FVHD_GELU_C2 9.945140159e-03f
-#define FVHD_GELU_C3 -1.168552637e-03f
-#define FVHD_GELU_C4 1.084709610e-04f
-#define FVHD_GELU_C5 -7.841504780e-06f
-#define FVHD_GELU_C6 4.224180292e-07f
-#define FVHD_GELU_C7 -1.572596130e-08f
-#define FVHD_GELU_C8 3.561182860e-10f
-#define FVHD_GELU_C9 -3.658831230e-12f
+//   Phi(x) = 0.5 + xc * Q(xc^2),  xc = clamp(x, -4, 4),  Q = degree-7 polynomial: minimax fit (LP on 6000 Chebyshev nodes
+//   of [0, 4]) under the constraint Phi(4) = 1, with C0 nudged by 3e-7 so that the fp32 Horner chain gives Q(16) = 0.125
+//   EXACTLY: Phi(+-4) = 1 / 0 bit-exactly, i.e. gelu(x) = x for x >= 4 and 0 for x <= -4 whatever the magnitude of the
+//   pre-activation (the round-1 degree-9 fit saturated at Phi(-4) = 3.2e-5: gelu(-60) = -1.9e-3).
+//   |Phi error| <= 3.3e-5 on [-4, 4] (= 1 - Phi(4): the price of the exact tails), |gelu error| <= 1.3e-4 absolute,
+//   <= 5e-5 relative for x > 0: 1/40 of the bf16 half-ulp every activation is rounded with right after.
+// 11 full-rate VALU per value (v_med3, v_mul, 7 v_fma, v_fma, v_mul); no v_rcp / v_exp (quarter rate).  The ConvFFN
+// kernels spend 14-47 % of their chunk loop on it (tools/ubench/ffn_mix.hip), hence the low degree.
+#define FVHD_GELU_C0 3.988050222e-01f
+#define FVHD_GELU_C1 -6.606452912e-02f
+#define FVHD_GELU_C2 9.582614526e-03f
+#define FVHD_GELU_C3 -1.021786709e-03f
+#define FVHD_GELU_C4 7.637563249e-05f
+#define FVHD_GELU_C5 -3.731796596e-06f
+#define FVHD_GELU_C6 1.056969481e-07f
+#define FVHD_GELU_C7 -1.304839459e-09f
 FVHD_DEV float gelu_erf(float x) {
     const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
     const float u = xc * xc;
-    float q = __builtin_fmaf(FVHD_GELU_C9, u, FVHD_GELU_C8);
-    q = __builtin_fmaf(q, u, FVHD_GELU_C7);
-    q = __builtin_fmaf(q, u, FVHD_GELU_C6);
+    float q = __builtin_fmaf(FVHD_GELU_C7, u, FVHD_GELU_C6);
     q = __builtin_fmaf(q, u, FVHD_GELU_C5);
     q = __builtin_fmaf(q, u, FVHD_GELU_C4);
     q = __builtin_fmaf(q, u, FVHD_GELU_C3);
@@ -92,11 +88,66 @@ FVHD_DEV void glds16(const void* gsrc, unsigned lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// same under a wave-uniform predicate WITHOUT a branch (a branch would split the caller's hand-pinned basic block and let
+// LLVM sink the VALU work scheduled around it): `mask` = all ones or zero replaces EXEC for the one instruction
+FVHD_DEV void glds16_masked(const void* gsrc, unsigned lds_dst, unsigned mask32)      // mask32: 0xffffffff or 0, from readfirstlane
+{
+    unsigned keep;
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, %4\n\t"
+                 "global_load_lds_dwordx4 %2, off\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex) : "v"(gsrc), "s"(lds_dst), "s"(mask32) : "memory");
+}
 // same, address = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset
 FVHD_DEV void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst)
 {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// 4 B/lane variant: used as an L2 prefetch ("touch": every lane names one 128-B line, the bytes land in a scratch LDS
+// area nobody reads) - no VGPR destination, so nothing to keep alive or to wait for beyond the usual vmcnt
+FVHD_DEV void glds4(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// NP (<= 4) consecutive 1-KiB pieces in ONE statement: LDS [lds_dst + 1024 i, +1 KiB) <- global sbase + voff + 1024 i.  The
+// instruction offset of global_load_lds advances the global AND the LDS address (tools/ubench/dma_offset.hip), so one M0
+// setting serves four pieces: 2 + NP instructions instead of 5 NP, and no VALU address arithmetic at all (saddr form).
+template <int NP> FVHD_DEV void glds16_run(const void* sbase, unsigned voff, unsigned lds_dst)
+{
+    static_assert(NP >= 1 && NP <= 4, "13-bit instruction offset");
+    unsigned keep;
+    if constexpr (NP == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else if constexpr (NP == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else if constexpr (NP == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else glds16_s(sbase, voff, lds_dst);
+}
+// the same run under a wave-uniform predicate without a branch (glds16_masked): mask32 = 0xffffffff or 0
+template <int NP> FVHD_DEV void glds16_run_masked(const void* sbase, unsigned voff, unsigned lds_dst, unsigned mask32)
+{
+    static_assert(NP == 2 || NP == 4, "instantiated sizes");
+    unsigned keep;
+    unsigned long long ex;
+    if constexpr (NP == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\tglobal_load_lds_dwordx4 %2, %3 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %2, %3 offset:3072\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask32) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b32 exec_lo, %5\n\ts_mov_b32 exec_hi, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask32) : "memory");
 }
 FVHD_DEV unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }

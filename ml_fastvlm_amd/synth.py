@@ -48,13 +48,24 @@ def _normal(shape, std, g):
     return torch.randn(shape, generator=g, dtype=torch.float32) * std
 
 
-def synthetic_tensor(key: str, shape, kind: str, seed: int) -> torch.Tensor:
+# "stress" (default): the gains above.  "mild": a well-conditioned set - no gains on the non-residual convs and qkv, small
+# layer scales and mixer branches - on which the reference's OWN bf16 execution stays within rel-L2 1e-2 of its fp32 one
+# (measured by oracle/make_golden.py --mild), so that the whole-tower GPU output can be held to SURVEY.md 8c's
+# rel-L2 <= 1e-2 / cosine >= 0.9999 end to end (tests/test_gpu_tower.py).
+PROFILES = {
+    "stress": {"ls": (0.1, 0.6), "branch": 0.3, "stem": 3.0, "down": 2.5, "exp": 3.0, "qkv": 3.0},
+    "mild": {"ls": (0.02, 0.12), "branch": 0.1, "stem": 2.0, "down": 2.0, "exp": 2.0, "qkv": 1.5},
+}
+
+
+def synthetic_tensor(key: str, shape, kind: str, seed: int, profile: str = "stress") -> torch.Tensor:
     g = _gen(seed, key)
+    pf = PROFILES[profile]
     leaf = key.rsplit(".", 1)[-1]
     if kind == "buffer_i64":
         return torch.zeros(shape, dtype=torch.int64)
     if "layer_scale" in leaf:
-        return _uniform(shape, 0.1, 0.6, g)
+        return _uniform(shape, pf["ls"][0], pf["ls"][1], g)
     if ".bn." in key or ".norm." in key:
         if leaf == "weight":
             return _uniform(shape, 0.8, 1.2, g)
@@ -74,16 +85,16 @@ def synthetic_tensor(key: str, shape, kind: str, seed: int) -> torch.Tensor:
             key.startswith("network.") and key.count(".") == 3 and key.endswith(".reparam_conv.weight")
         ):
             k = shape[-1]
-            w *= 0.3
+            w *= pf["branch"]
             w[:, 0, k // 2, k // 2] += 1.0
         elif key.startswith("patch_embed."):
-            w *= 3.0            # stem: GELU roughly halves small activations
+            w *= pf["stem"]     # stem: GELU roughly halves small activations
         elif ".proj.0." in key or ".proj.1." in key:
-            w *= 2.5            # PatchEmbed convs (non-residual)
+            w *= pf["down"]     # PatchEmbed convs (non-residual)
         elif key == "conv_exp.reparam_conv.weight":
-            w *= 3.0
+            w *= pf["exp"]
         elif key.endswith("token_mixer.qkv.weight"):
-            w *= 3.0            # logit std ~3: a peaky softmax that exercises the online rescale
+            w *= pf["qkv"]      # stress: logit std ~3, a peaky softmax that exercises the online rescale
         return w
     if leaf == "bias":
         # bound from the sibling weight's fan_in is not known here; 0.05 keeps things O(1)
@@ -91,11 +102,11 @@ def synthetic_tensor(key: str, shape, kind: str, seed: int) -> torch.Tensor:
     raise KeyError(f"no synthetic rule for {key}")
 
 
-def synthetic_state_dict(seed: int = 1234) -> "OrderedDict[str, torch.Tensor]":
+def synthetic_state_dict(seed: int = 1234, profile: str = "stress") -> "OrderedDict[str, torch.Tensor]":
     """FastViT-relative keys (`patch_embed.0.reparam_conv.weight`, ...)."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for key, (shape, kind) in spec.param_spec().items():
-        sd[key] = synthetic_tensor(key, shape, kind, seed)
+        sd[key] = synthetic_tensor(key, shape, kind, seed, profile)
     return sd
 
 

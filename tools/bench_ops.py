@@ -38,7 +38,9 @@ def timeit(fn, iters=20, warm=10):
     return a.elapsed_time(b) / iters * 1e-3
 
 
-def bench_ffn(B=32, variants=True):
+def bench_ffn(B=32):
+    """fused ConvFFN at the B = 32 stage shapes.  FVHD_FFN_PERSIST=1 selects the persistent kernels (read once per process: run
+    this twice for an A/B)."""
     for Cc, H in ((96, 256), (192, 128), (384, 64)):
         M, HID = B * H * H, 4 * Cc
         g = torch.Generator().manual_seed(0)
@@ -56,18 +58,47 @@ def bench_ffn(B=32, variants=True):
         ls = torch.full((Cc,), 0.01, device=DEV)
         t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
         fl, by = 16.0 * M * Cc * Cc, 6.0 * M * Cc
-        print(f"ffn_fused C={Cc:4d} M={M:8d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.1f} GB/s (algorithmic)")
-        if variants:
-            raw = C.CDLL(_lib.LIB_PATH)
-            f = raw.fvhd_debug_ffn_variant
-            f.argtypes = [C.c_void_p] * 8 + [C.c_int] * 6
-            names = {0: "full", 1: "no weight DMA", 2: "no GELU", 3: "no DMA, no GELU", 12: "no MFMA", 13: "no MFMA, no DMA", 15: "LDS reads + barriers only", 16: "prologue + 4 edge iterations + epilogue only"}
-            combos = {384: [(1, 4, 0, 3), (1, 4, 3, 3), (1, 4, 15, 3), (1, 4, 16, 3)],
-                      192: [(1, 4, 0, 3), (1, 4, 16, 3)],
-                      96: [(1, 4, 0, 3), (1, 4, 16, 3)]}[Cc]
-            for nb, wv, v, pf in combos:
-                tv = timeit(lambda: f(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc, nb, wv, v, pf))
-                print(f"    NB={nb} waves={wv} variant {v:2d} pf={pf} ({names[v]:26s}): {tv*1e6:9.1f} us  {fl/tv/1e12:7.1f} TF/s")
+        print(f"ffn_fused C={Cc:4d} M={M:8d} persist={os.environ.get('FVHD_FFN_PERSIST', '0')}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.1f} GB/s (algorithmic)")
+
+
+def ffn_stamps(Cc=192):
+    """ablation library only (FVHD_LIB=libfvhd_ablate.so, FVHD_FFN_VARIANT=128|131|143): s_memtime stamps of workgroup 0"""
+    import numpy as np
+    H = {96: 256, 192: 128}[Cc]
+    M, HID = 32 * H * H, 4 * Cc
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+    X = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
+    W1 = (torch.randn(HID, Cc, generator=g) * Cc ** -0.5).to(torch.bfloat16).float().contiguous()
+    W2 = (torch.randn(Cc, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).float().contiguous()
+    nch, che = HID // 32, 32 * Cc
+    i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
+    i2 = torch.empty(nch * che, dtype=torch.bfloat16)
+    _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
+    i1, i2 = i1.to(DEV), i2.to(DEV)
+    b1 = torch.randn(HID, generator=g).to(DEV) * 0.1
+    b2 = torch.randn(Cc, generator=g).to(DEV) * 0.1
+    ls = torch.full((Cc,), 0.01, device=DEV)
+    for _ in range(3):
+        _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc))
+    torch.cuda.synchronize()
+    raw = C.CDLL(_lib.LIB_PATH)
+    buf = (C.c_uint * (8 * 40 * 4))()
+    assert raw.fvhd_debug_ffn_stamps(buf) == 0
+    st = np.array(buf, dtype=np.int64).reshape(8, 40, 4)
+    t0 = st[:, 0, 0].min()
+    print(f"C={Cc} variant {os.environ.get('FVHD_FFN_VARIANT')}: per wave, iteration pairs 4..35: mean cycles  wait+barrier | even body | hooks | odd half (to next pair)")
+    for w in range(8):
+        s = st[w, 4:36]
+        nxt = st[w, 5:37, 0]
+        d = lambda a, b: float(((b - a) & 0xffffffff).mean())
+        print(f"  wave {w}: {d(s[:, 0], s[:, 1]):8.0f} | {d(s[:, 1], s[:, 2]):8.0f} | {d(s[:, 2], s[:, 3]):8.0f} | {d(s[:, 3], nxt):8.0f}   pair total {d(s[:, 0], nxt):8.0f}")
+    w = 0
+    print("  wave 0 pairs 8..20 (wait, body, hooks, odd):", [[int((st[w, i, 1] - st[w, i, 0]) & 0xffffffff), int((st[w, i, 2] - st[w, i, 1]) & 0xffffffff),
+                                                             int((st[w, i, 3] - st[w, i, 2]) & 0xffffffff), int((st[w, i + 1, 0] - st[w, i, 3]) & 0xffffffff)] for i in range(8, 20)])
+    w = 7
+    print("  wave 7 pairs 8..20 (wait, body, hooks, odd):", [[int((st[w, i, 1] - st[w, i, 0]) & 0xffffffff), int((st[w, i, 2] - st[w, i, 1]) & 0xffffffff),
+                                                             int((st[w, i, 3] - st[w, i, 2]) & 0xffffffff), int((st[w, i + 1, 0] - st[w, i, 3]) & 0xffffffff)] for i in range(8, 20)])
 
 
 def bench_stem(B=32, R=1024):
@@ -81,33 +112,6 @@ def bench_stem(B=32, R=1024):
     t2 = timeit(lambda: _lib.check(lib.fvhd_op_stem_fused(stream(), p(img), 2, p(out), p(w0), p(b0), p(w1), p(b1), B, R)))
     by = 2.0 * (img.numel() + out.numel())
     print(f"stem[0] {t0*1e6:8.1f} us + stem[1] {t1*1e6:8.1f} us = {(t0+t1)*1e6:8.1f} us;  fused {t2*1e6:8.1f} us ({by/t2/1e9:6.1f} GB/s algorithmic)")
-
-
-def bench_ffn_stagger(B=32):
-    """start offset of the second workgroup per CU (units of s_sleep 127 ~ 4 us): kernel time of the production launch"""
-    raw = C.CDLL(_lib.LIB_PATH)
-    for Cc, H in ((384, 64), (96, 256), (192, 128)) if len(sys.argv) > 2 and sys.argv[2] == "all" else ((384, 64),):
-        M, HID = B * H * H, 4 * Cc
-        g = torch.Generator().manual_seed(0)
-        A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
-        X = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
-        W1 = (torch.randn(HID, Cc, generator=g) * Cc ** -0.5).to(torch.bfloat16).float().contiguous()
-        W2 = (torch.randn(Cc, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).float().contiguous()
-        nch, che = HID // 32, 32 * Cc
-        i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
-        i2 = torch.empty(nch * che, dtype=torch.bfloat16)
-        _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
-        i1, i2 = i1.to(DEV), i2.to(DEV)
-        b1 = torch.randn(HID, generator=g).to(DEV) * 0.1
-        b2 = torch.randn(Cc, generator=g).to(DEV) * 0.1
-        ls = torch.full((Cc,), 0.01, device=DEV)
-        for st in (0, 0, 1, 2, 3, 4, 5, 7, 9, 12, 16):
-            raw.fvhd_debug_set_ffn_stagger(st, st)
-            raw.fvhd_debug_set_ffn_stagger384(st)
-            t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
-            print(f"ffn_fused C={Cc:4d} stagger {st:2d}: {t*1e6:9.1f} us  {16.0 * M * Cc * Cc / t / 1e12:7.1f} TF/s")
-    raw.fvhd_debug_set_ffn_stagger(3, 3)
-    raw.fvhd_debug_set_ffn_stagger384(0)
 
 
 def bench_dw(B=32, modes=(0,)):
@@ -210,71 +214,7 @@ def bench_attn(B=32):
         print(f"attention N={N:5d} C={Cc:5d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s")
 
 
-def bench_overlap(B=16):
-    """Does the hardware co-schedule an MFMA-bound and a VALU-bound kernel from two streams on the same CUs?
-    fused FFN (C=192: 236 VGPRs, 51 KB LDS) beside dw7x7 (173 VGPRs, 77 KB LDS): sequential vs concurrent time."""
-    Cc, H = 192, 128
-    M, HID = B * H * H, 4 * Cc
-    g = torch.Generator().manual_seed(0)
-    A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
-    X = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
-    W1 = (torch.randn(HID, Cc, generator=g) * Cc ** -0.5).to(torch.bfloat16).float().contiguous()
-    W2 = (torch.randn(Cc, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).float().contiguous()
-    nch, che = HID // 32, 32 * Cc
-    i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
-    i2 = torch.empty(nch * che, dtype=torch.bfloat16)
-    _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
-    i1, i2 = i1.to(DEV), i2.to(DEV)
-    b1, b2, ls = torch.zeros(HID, device=DEV), torch.zeros(Cc, device=DEV), torch.full((Cc,), 0.01, device=DEV)
-    x2 = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
-    y2 = torch.empty_like(x2)
-    w = torch.randn(49, Cc, device=DEV)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-
-    def sp(s):
-        return C.c_void_p(s.cuda_stream)
-
-    def ffn(s, n=4):
-        for _ in range(n):
-            _lib.check(lib.fvhd_op_ffn_fused(sp(s), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc))
-
-    def dw(s, n=4):
-        for _ in range(n):
-            _lib.check(lib.fvhd_op_dwconv(sp(s), p(x2), p(y2), p(w), None, B, H, H, Cc, 7, 1, 1, 0))
-
-    def wall(fn, reps=5):
-        fn()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        cur = torch.cuda.current_stream()
-        a.record(cur)
-        s1.wait_event(a)
-        s2.wait_event(a)
-        for _ in range(reps):
-            fn()
-        e1, e2 = torch.cuda.Event(), torch.cuda.Event()
-        e1.record(s1)
-        e2.record(s2)
-        cur.wait_event(e1)
-        cur.wait_event(e2)
-        b.record(cur)
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / reps * 1e3
-
-    raw = C.CDLL(_lib.LIB_PATH)
-    for pad in (0, 31 * 1024):
-        raw.fvhd_debug_set_ffn_lds_pad(pad)
-        for _ in range(2):
-            t_f = wall(lambda: ffn(s1))
-            t_d = wall(lambda: dw(s2))
-            t_seq = wall(lambda: (ffn(s1), dw(s1)))
-            t_par = wall(lambda: (ffn(s1), dw(s2)))
-        print(f"overlap test, ffn LDS pad {pad:6d} B (4 launches each): ffn alone {t_f:8.1f} us, dw7 alone {t_d:8.1f} us, "
-              f"same stream {t_seq:8.1f} us, two streams {t_par:8.1f} us")
-    raw.fvhd_debug_set_ffn_lds_pad(0)
-
-
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_plain": lambda: bench_ffn(variants=False), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "ffn_stagger": bench_ffn_stagger, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn, "overlap": bench_overlap}[w]()
+        {"ffn": bench_ffn, "ffn_stamps": ffn_stamps, "ffn_stamps96": lambda: ffn_stamps(96), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()
