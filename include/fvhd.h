@@ -49,6 +49,12 @@ const char* fvhd_last_error(void);
 int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch);
 void fvhd_destroy(fvhd_ctx* ctx);
 
+/* Size the workspace for `max_batch` images NOW.  Growing it (here, or implicitly when a larger batch reaches fvhd_encode*)
+ * synchronises the device, frees and re-allocates the arena and drops the cached graphs - the only place where the library
+ * synchronises.  It is refused while the caller's stream is being captured: reserve before capturing.  Every entry point
+ * that takes a context runs on the context's device and restores the caller's current device before returning. */
+int fvhd_reserve(fvhd_ctx* ctx, int max_batch);
+
 /* Hand one tensor of the reference's inference-mode state dict to the library
  * (key relative to the FastViT module, e.g. "network.7.0.token_mixer.qkv.weight"; the 629 keys of
  * tests/golden/keys.json).  `host_data` is contiguous fp32 HOST memory in the reference's own

@@ -29,6 +29,7 @@ def _declare(lib) -> None:
         "fvhd_last_error": (C.c_char_p, []),
         "fvhd_create": (ci, [C.POINTER(vp), ci, ci, ci]),
         "fvhd_destroy": (None, [vp]),
+        "fvhd_reserve": (ci, [vp, ci]),
         "fvhd_set_tensor": (ci, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ci]),
         "fvhd_finalize_weights": (ci, [vp]),
         "fvhd_set_projector": (ci, [vp, vp, vp, vp, vp, ci, ci]),
@@ -123,6 +124,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def reserve(self, max_batch: int) -> None:
+        """size the workspace for `max_batch` images now (synchronises; not allowed during stream capture)"""
+        check(load().fvhd_reserve(self._h, int(max_batch)), "fvhd_reserve")
 
     def set_tensor(self, key: str, t) -> None:
         import torch

@@ -260,6 +260,25 @@ bool pack_ffn(fvhd_ctx* c, Packer& pk, const std::string& p, const std::string& 
     return pack_vec(c, pk, ls_key, {C, 1, 1}, &out->ls);
 }
 
+// Every entry point that takes a context runs with the CONTEXT's device current and restores the caller's on exit: a tower on
+// cuda:1 must neither allocate its arena on cuda:0 nor leave cuda:1 current for the caller's next torch allocation.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define FVHD_ON_DEVICE(c)                                              \
+    DeviceGuard _guard((c)->device);                                   \
+    if (_guard.err != hipSuccess) return hip_fail("hipSetDevice", _guard.err)
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Ws {   // workspace carve-up for batch B
@@ -295,9 +314,16 @@ void clear_graphs(fvhd_ctx* c)
     c->graphs.clear();
 }
 
-int ensure_ws(fvhd_ctx* c, int B)
+// Growing the arena synchronises the device, frees and re-allocates: never legal while `st` is being captured into a graph
+// (the caller must fvhd_reserve() the batch size before it starts capturing).
+int ensure_ws(fvhd_ctx* c, int B, hipStream_t st = nullptr, bool check_capture = false)
 {
     if (c->ws && B <= c->ws_batch && c->hidden <= c->ws_hidden) return 0;
+    if (check_capture) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail("fvhd: the workspace must grow for this batch size but the stream is being captured - call fvhd_reserve(ctx, batch) before capturing");
+    }
     clear_graphs(c);                         // cached graphs point into the old arena
     const int nb = B > c->ws_batch ? B : c->ws_batch;
     const size_t need = carve(c, nullptr, nb, c->hidden).total;
@@ -443,17 +469,11 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
     return fail("run_step: bad step kind");
 }
 
-int prepare(fvhd_ctx* c, int B)
+int prepare(fvhd_ctx* c, int B, hipStream_t st)          // the caller holds a DeviceGuard
 {
     if (!c->finalized) return fail("fvhd: weights not finalized (call fvhd_finalize_weights)");
     if (B <= 0) return fail("fvhd: batch must be positive");
-    int dev = -1;
-    (void)hipGetDevice(&dev);
-    if (dev != c->device) {
-        hipError_t he = hipSetDevice(c->device);
-        if (he != hipSuccess) return hip_fail("hipSetDevice", he);
-    }
-    return ensure_ws(c, B);
+    return ensure_ws(c, B, st, true);
 }
 
 // the part of workspace `w` (carved for `total` images) that belongs to the images [b0, total)
@@ -500,7 +520,7 @@ int run_range(fvhd_ctx* c, hipStream_t st, int first, int last, bool dualmode, c
 int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out, int out_dtype, hipStream_t st)
 {
     if (img_dtype < 0 || img_dtype > 2 || out_dtype < 0 || out_dtype > 2) return fail("fvhd_encode: bad dtype");
-    int e = prepare(c, B);
+    int e = prepare(c, B, st);
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
     const int n = (int)c->m.steps.size();
@@ -600,8 +620,8 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail("fvhd_create: no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= n) return fail("fvhd_create: bad device index");
-    e = hipSetDevice(device);
-    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    DeviceGuard guard(device);               // (only validates the device here: nothing is allocated before fvhd_finalize_weights)
+    if (guard.err != hipSuccess) return hip_fail("hipSetDevice", guard.err);
     fvhd_ctx* c = new fvhd_ctx();
     c->device = device;
     c->R = image_size;
@@ -618,7 +638,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
 void fvhd_destroy(fvhd_ctx* c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -712,8 +732,8 @@ int fvhd_finalize_weights(fvhd_ctx* c)
         else m.steps.push_back(Step{S_HEAD, s, 0, kDims[s], hd, kOutDim, hd});
     }
 
-    hipError_t e = hipSetDevice(c->device);
-    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    FVHD_ON_DEVICE(c);
+    hipError_t e;
     (void)hipDeviceSynchronize();
     clear_graphs(c);                         // cached graphs point at the old packed weights
     if (c->wdev) (void)hipFree(c->wdev);
@@ -732,12 +752,13 @@ int fvhd_set_projector(fvhd_ctx* c, const float* w0, const float* b0, const floa
 {
     if (!c || !w0 || !b0 || !w2 || !b2) return fail("fvhd_set_projector: bad argument");
     if (mm_hidden % 32 || hidden % 32) return fail("fvhd_set_projector: mm_hidden and hidden must be multiples of 32");
+    if (hidden <= 0 || mm_hidden <= 0) return fail("fvhd_set_projector: sizes must be positive");
     Packer pk;
     GemmW p0, p2;
     p0.w = pk.add_bf16(w0, (size_t)hidden * mm_hidden); p0.b = pk.add_f32(b0, hidden); p0.N = hidden; p0.K = mm_hidden; p0.has_bias = true;
     p2.w = pk.add_bf16(w2, (size_t)hidden * hidden); p2.b = pk.add_f32(b2, hidden); p2.N = hidden; p2.K = hidden; p2.has_bias = true;
-    hipError_t e = hipSetDevice(c->device);
-    if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+    FVHD_ON_DEVICE(c);
+    hipError_t e;
     (void)hipDeviceSynchronize();
     if (c->pdev) (void)hipFree(c->pdev);
     c->pdev = nullptr;
@@ -752,6 +773,7 @@ int fvhd_set_projector(fvhd_ctx* c, const float* w0, const float* b0, const floa
 int fvhd_encode(fvhd_ctx* c, const void* images, int img_dtype, int batch, void* tokens_out, int out_dtype, fvhd_stream_t stream)
 {
     if (!c || !images || !tokens_out) return fail("fvhd_encode: NULL argument");
+    FVHD_ON_DEVICE(c);
     return encode_impl(c, images, img_dtype, batch, tokens_out, out_dtype, (hipStream_t)stream);
 }
 
@@ -760,8 +782,9 @@ int fvhd_project(fvhd_ctx* c, const void* tokens, int in_dtype, int rows, void* 
     if (!c || !tokens || !out) return fail("fvhd_project: NULL argument");
     if (!c->pdev) return fail("fvhd_project: projector weights not set (call fvhd_set_projector)");
     if (rows <= 0) return fail("fvhd_project: rows must be positive");
+    FVHD_ON_DEVICE(c);
     const int Tn = fvhd_num_tokens(c);
-    int e = ensure_ws(c, (rows + Tn - 1) / Tn);
+    int e = ensure_ws(c, (rows + Tn - 1) / Tn, (hipStream_t)stream, true);
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
     return project_impl(c, tokens, in_dtype, rows, out, out_dtype, (hipStream_t)stream, w);
@@ -771,12 +794,24 @@ int fvhd_encode_images(fvhd_ctx* c, const void* images, int img_dtype, int batch
 {
     if (!c || !images || !out) return fail("fvhd_encode_images: NULL argument");
     if (!c->pdev) return fail("fvhd_encode_images: projector weights not set (call fvhd_set_projector)");
-    int e = ensure_ws(c, batch);
+    if (c->mm_hidden != kOutDim) return fail("fvhd_encode_images: the projector was set with mm_hidden != 3072 (the tower's token width)");
+    if (batch <= 0) return fail("fvhd_encode_images: batch must be positive");
+    FVHD_ON_DEVICE(c);
+    int e = ensure_ws(c, batch, (hipStream_t)stream, true);
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
     e = encode_impl(c, images, img_dtype, batch, w.tok, FVHD_BF16, (hipStream_t)stream);
     if (e) return e;
     return project_impl(c, w.tok, FVHD_BF16, batch * fvhd_num_tokens(c), out, out_dtype, (hipStream_t)stream, w);
+}
+
+int fvhd_reserve(fvhd_ctx* c, int max_batch)
+{
+    if (!c) return fail("fvhd_reserve: ctx is NULL");
+    if (max_batch <= 0) return fail("fvhd_reserve: max_batch must be positive");
+    FVHD_ON_DEVICE(c);
+    if (max_batch > c->max_batch) c->max_batch = max_batch;
+    return c->finalized ? ensure_ws(c, max_batch) : 0;    // before fvhd_finalize_weights it only raises the size allocated there
 }
 
 int fvhd_num_steps(const fvhd_ctx* c) { return (c && c->finalized) ? (int)c->m.steps.size() : 0; }
@@ -799,7 +834,8 @@ int fvhd_step_info(const fvhd_ctx* c, int step, int* kind, int* stage, int* bloc
 int fvhd_run_steps(fvhd_ctx* c, int first, int last, const void* x_in, int batch, void* x_out, fvhd_stream_t stream)
 {
     if (!c || !x_in || !x_out) return fail("fvhd_run_steps: NULL argument");
-    int e = prepare(c, batch);
+    FVHD_ON_DEVICE(c);
+    int e = prepare(c, batch, (hipStream_t)stream);
     if (e) return e;
     const int n = (int)c->m.steps.size();
     if (first < 0 || last >= n || first > last) return fail("fvhd_run_steps: bad step range");
@@ -867,6 +903,7 @@ static int drain(fvhd_ctx* c)
 int fvhd_profile_reset(fvhd_ctx* c)
 {
     if (!c) return fail("fvhd_profile_reset: ctx is NULL");
+    FVHD_ON_DEVICE(c);
     int e = drain(c);
     for (int i = 0; i < C_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
     return e;
@@ -875,6 +912,7 @@ int fvhd_profile_reset(fvhd_ctx* c)
 int fvhd_profile_read(fvhd_ctx* c, int max_classes, const char** names, double* ms, int64_t* launches, int* n_classes)
 {
     if (!c || !names || !ms || !launches || !n_classes) return fail("fvhd_profile_read: NULL argument");
+    FVHD_ON_DEVICE(c);
     int e = drain(c);
     if (e) return e;
     int n = C_COUNT < max_classes ? C_COUNT : max_classes;

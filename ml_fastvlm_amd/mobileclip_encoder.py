@@ -84,6 +84,16 @@ class FastViTHDWeights(nn.Module):
         self.model.load_state_dict(sd, strict=True)
 
 
+class _DirtyHook:
+    """load_state_dict post-hook (a picklable callable, unlike a lambda): any load into the subtree invalidates the packed copy."""
+
+    def __init__(self, tower):
+        self.tower = tower
+
+    def __call__(self, module, incompatible_keys):
+        self.tower._mark_dirty()
+
+
 class MobileCLIPVisionTower(nn.Module):
     def __init__(self, vision_tower: str, args, delay_load: bool = False):
         super().__init__()
@@ -93,9 +103,15 @@ class MobileCLIPVisionTower(nn.Module):
         self.input_image_size = int(vision_tower.split("_")[-1])
         # MI355X-only option (no counterpart in the reference): e4m3 MFMA operands in the MHSA core, the "fp8 MFMA attention
         # path" of BASELINE.json configs[4]; read from the config object like the reference reads its own switches
-        self.attention_fp8 = bool(getattr(args, "mm_vision_attention_fp8", False))
+        # Tri-state: None = leave the library's setting alone (fvhd_create reads FVHD_ATTN_FP8 / FVHD_GRAPH from the environment,
+        # INTEGRATION.md); True / False = explicit, pushed to the context before every call.
+        fp8 = getattr(args, "mm_vision_attention_fp8", None)
+        self.attention_fp8 = None if fp8 is None else bool(fp8)
         # ... and hipGraph replay of the tower's interior launches (include/fvhd.h: fvhd_set_graph), for launch-bound batches
-        self.hip_graph = bool(getattr(args, "mm_vision_hip_graph", False))
+        graph = getattr(args, "mm_vision_hip_graph", None)
+        self.hip_graph = None if graph is None else bool(graph)
+        # expected batch size (sizes the library's workspace up front; it grows geometrically when a larger batch arrives)
+        self._batch_hint = max(1, int(getattr(args, "mm_vision_max_batch", 1) or 1))
         self._ctx: Optional[_lib.Context] = None
         self._ctx_key = None
         self._dirty = True
@@ -129,7 +145,7 @@ class MobileCLIPVisionTower(nn.Module):
         # load_state_dict may be called on the tower, on an ancestor (the whole LLaVA model) or on any
         # descendant (tests load into `.vision_tower.model`): hook every module of the subtree.
         for mod in self.modules():
-            mod.register_load_state_dict_post_hook(lambda module, incompatible: self._mark_dirty())
+            mod.register_load_state_dict_post_hook(_DirtyHook(self))
         self.is_loaded = True
         self._dirty = True
 
@@ -153,7 +169,7 @@ class MobileCLIPVisionTower(nn.Module):
         if self._ctx is None or self._ctx_key != key:
             if self._ctx is not None:
                 self._ctx.close()
-            self._ctx = _lib.Context(idx, self.input_image_size, max_batch=1)
+            self._ctx = _lib.Context(idx, self.input_image_size, max_batch=self._batch_hint)
             self._ctx_key = key
             self._dirty = True
             self._projector_src = None
@@ -163,9 +179,26 @@ class MobileCLIPVisionTower(nn.Module):
                     self._ctx.set_tensor(k, v)
             self._ctx.finalize()
             self._dirty = False
-        self._ctx.set_attention_fp8(self.attention_fp8)
-        self._ctx.set_graph(self.hip_graph)
+        if self.attention_fp8 is not None:
+            self._ctx.set_attention_fp8(self.attention_fp8)
+        if self.hip_graph is not None:
+            self._ctx.set_graph(self.hip_graph)
         return self._ctx
+
+    # The ctypes handle is process-local state, not model state: copies / pickles of a tower start without a context and
+    # re-pack their weights on first use (copy.deepcopy of a model after its first forward used to fail on the handle).
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_ctx"], st["_ctx_key"], st["_dirty"], st["_projector_src"] = None, None, True, None
+        return st
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():       # (the _DirtyHook objects are copied along and point at the copy: memo)
+            object.__setattr__(new, k, copy.deepcopy(v, memo))
+        return new
 
     def sync_weights(self) -> None:
         """Force a re-pack (e.g. after in-place edits of parameters that no hook can see)."""
@@ -179,15 +212,29 @@ class MobileCLIPVisionTower(nn.Module):
         with torch.no_grad():
             return self.forward_images(images)
 
-    def _encode(self, images: torch.Tensor) -> torch.Tensor:
-        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != images.shape[3] \
-                or images.shape[2] != self.input_image_size:
+    def _check_images(self, images: torch.Tensor) -> torch.Tensor:
+        """Shape / dtype / device normalisation shared by every entry point: the library trusts B and the context's R, so a
+        mis-shaped tensor must be rejected HERE (the reference raises a shape error inside its first conv)."""
+        if not isinstance(images, torch.Tensor) or images.dim() != 4 or images.shape[1] != 3 \
+                or images.shape[2] != images.shape[3] or images.shape[2] != self.input_image_size or images.shape[0] < 1:
             raise ValueError(f"expected images of shape [B,3,{self.input_image_size},{self.input_image_size}], "
-                             f"got {tuple(images.shape)}")
-        ctx = self._context()
+                             f"got {tuple(images.shape) if isinstance(images, torch.Tensor) else type(images)}")
         images = images.to(device=self.device).contiguous()
         if images.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             images = images.float()
+        return images
+
+    def _grow(self, ctx, batch: int) -> None:
+        """Workspace growth synchronises the device and re-allocates (include/fvhd.h): do it geometrically, not per batch size."""
+        if batch > self._batch_hint:
+            while self._batch_hint < batch:
+                self._batch_hint *= 2
+            ctx.reserve(self._batch_hint)
+
+    def _encode(self, images: torch.Tensor) -> torch.Tensor:
+        images = self._check_images(images)
+        ctx = self._context()
+        self._grow(ctx, images.shape[0])
         out = torch.empty((images.shape[0], ctx.num_tokens, self.hidden_size), device=images.device, dtype=images.dtype)
         ctx.encode(images, out)
         return out
@@ -207,15 +254,19 @@ class MobileCLIPVisionTower(nn.Module):
     # ---- encode_images = tower -> projector in one library call (llava_arch.py:141-144) -------------
     def encode_images_with_projector(self, images: torch.Tensor, projector: nn.Module) -> torch.Tensor:
         with torch.no_grad():
-            ctx = self._context()
+            images = self._check_images(images)
             w0, b0, w2, b2 = projector[0].weight, projector[0].bias, projector[2].weight, projector[2].bias
+            hid = w0.shape[0]
+            if w0.dim() != 2 or w0.shape[1] != self.hidden_size or tuple(w2.shape) != (hid, hid) \
+                    or tuple(b0.shape) != (hid,) or tuple(b2.shape) != (hid,):
+                raise ValueError(f"mlp2x_gelu projector must be Linear({self.hidden_size}, H) -> GELU -> Linear(H, H); got weights "
+                                 f"{tuple(w0.shape)}, {tuple(w2.shape)}")
+            ctx = self._context()
             src = tuple((t.data_ptr(), t._version, t.dtype) for t in (w0, b0, w2, b2))
             if self._projector_src != src:
                 ctx.set_projector(w0, b0, w2, b2)
                 self._projector_src = src
-            images = images.to(device=self.device).contiguous()
-            if images.dtype not in (torch.float32, torch.float16, torch.bfloat16):
-                images = images.float()
+            self._grow(ctx, images.shape[0])
             out = torch.empty((images.shape[0], ctx.num_tokens, w0.shape[0]), device=images.device, dtype=images.dtype)
             ctx.encode_images(images, out)
             return out

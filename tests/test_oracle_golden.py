@@ -69,6 +69,21 @@ def test_oracle_matches_reference_r1536(golden_dir, synth_sd):
     assert 2e-2 < float(g["ref_bf16_rel_l2"]) < 5e-2
 
 
+def test_oracle_matches_reference_mild_weights(golden_dir):
+    """Second, well-conditioned weight set (synth profile "mild"): on it the reference's OWN bf16 execution is within 1e-2 of
+    its fp32 one, which is what lets tests/test_gpu_tower.py hold the GPU tower to SURVEY.md 8c's end-to-end tolerance."""
+    sd = synth.synthetic_state_dict(1234, "mild")
+    g = np.load(os.path.join(golden_dir, "tower_mild_r256_b2.npz"))
+    out = O.tower_forward(synth.synthetic_images(2, 256, seed=int(g["image_seed"])), sd)
+    assert _rel_l2(out, torch.from_numpy(g["out"])) < 2e-6
+    assert float(g["ref_bf16_rel_l2"]) <= 1e-2 and float(g["ref_bf16_cos"]) >= 0.9999
+    g = np.load(os.path.join(golden_dir, "tower_mild_r1024_b1.npz"))
+    out = O.tower_forward(synth.synthetic_images(1, 1024, seed=int(g["image_seed"])), sd)
+    assert _rel_l2(out[:, ::8], torch.from_numpy(g["out_tok8"])) < 2e-6
+    assert torch.allclose(out.double().pow(2).sum(-1).sqrt()[0], torch.from_numpy(g["token_l2"]), rtol=1e-5)
+    assert float(g["ref_bf16_rel_l2"]) <= 1e-2 and float(g["ref_bf16_cos"]) >= 0.9999
+
+
 def test_oracle_projector_h3584(golden_dir):
     """FastVLM-7B projector width (BASELINE.json configs[3])."""
     g = np.load(os.path.join(golden_dir, "projector_h3584.npz"))
@@ -106,3 +121,54 @@ def test_oracle_matches_live_reference_odd_shapes(synth_sd):
     ref64 = tower(x.double())
     got64 = O.tower_forward(x.double(), synth_sd, dtype=torch.float64)
     assert _rel_l2(got64, ref64) < 1e-12
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="reference tree not mounted")
+def test_install_into_llava_routes_the_reference_model_through_our_tower():
+    """BASELINE.json configs[0] plumbing: after install_into_llava() an UNMODIFIED LlavaQwen2ForCausalLM builds our tower
+    (llava_arch.py:34-36), its checkpoint keys `model.vision_tower.vision_tower.model.*` load strictly, and encode_images
+    (llava_arch.py:141-144) lands in encode_images_with_projector.  No GPU here: the library call itself must raise the
+    no-CPU-path error, not fall back."""
+    from types import SimpleNamespace
+    import ml_fastvlm_amd as fv
+    from ml_fastvlm_amd import builder
+    ref_import.install_timm_stub()
+    import sys
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    builder.install_into_llava()
+    from transformers import Qwen2Config
+    from llava.model.language_model.llava_qwen import LlavaConfig, LlavaQwen2ForCausalLM
+    import llava.model.llava_arch as arch
+    cfg = LlavaConfig(**Qwen2Config(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                    num_key_value_heads=2, max_position_embeddings=512).to_dict())
+    cfg.mm_vision_tower, cfg.mm_projector_type, cfg.mm_hidden_size = "mobileclip_l_256", "mlp2x_gelu", 3072
+    cfg.unfreeze_mm_vision_tower = True                      # llava_arch.py:35 builds with delay_load=True; this forces the load
+    model = LlavaQwen2ForCausalLM(cfg)
+    tower = model.get_vision_tower()
+    assert isinstance(tower, fv.MobileCLIPVisionTower) and tower.is_loaded
+    # the checkpoint's tower keys are the reference's (629 tensors under model.vision_tower.vision_tower.model.)
+    want = {"model.vision_tower.vision_tower.model." + k for k in spec.param_spec()}
+    have = {k for k in model.state_dict() if k.startswith("model.vision_tower.")}
+    assert have == want
+    sd = {"vision_tower.model." + k: v for k, v in synth.synthetic_state_dict(7).items()}
+    tower._dirty = False
+    missing, unexpected = tower.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected and tower._dirty, "a strict load into the tower must succeed and invalidate the packed copy"
+    # encode_images of the reference class now routes into the fused call
+    seen = {}
+
+    def spy(images, projector):
+        seen["shape"], seen["proj"] = tuple(images.shape), projector
+        return torch.zeros(images.shape[0], 16, cfg.hidden_size)
+    tower.encode_images_with_projector = spy
+    fake_dev = SimpleNamespace(device=model.get_model().mm_projector[0].weight.device)
+    assert fake_dev.device == tower.device
+    with torch.no_grad():
+        out = model.encode_images(torch.zeros(2, 3, 256, 256))
+    assert seen["shape"] == (2, 3, 256, 256) and seen["proj"] is model.get_model().mm_projector and out.shape == (2, 16, 64)
+    assert arch.LlavaMetaForCausalLM.encode_images.__name__ == "_encode_images"
+    # and without a HIP device the real call refuses instead of falling back to a CPU path
+    del tower.encode_images_with_projector
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        model.encode_images(torch.zeros(1, 3, 256, 256))

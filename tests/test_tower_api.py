@@ -48,7 +48,8 @@ def test_mi355x_options_default_off_and_read_from_args():
     """The two options that have no counterpart in the reference are opt-in, so a reference config object
     that knows nothing about them builds the parity path."""
     t = fv.MobileCLIPVisionTower("mobileclip_l_256", ARGS, delay_load=True)
-    assert t.attention_fp8 is False and t.hip_graph is False
+    assert t.attention_fp8 is None and t.hip_graph is None      # tri-state: None = "not set here" (the library default is off and its
+    #                                                             environment switches FVHD_ATTN_FP8 / FVHD_GRAPH stay in force)
     t = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_attention_fp8=True,
                                                                     mm_vision_hip_graph=1), delay_load=True)
     assert t.attention_fp8 is True and t.hip_graph is True
@@ -125,3 +126,34 @@ def test_surface_equals_live_reference():
     assert ref.dummy_feature.shape == mine.dummy_feature.shape
     assert type(ref.image_processor) is type(mine.image_processor)
     assert ref.image_processor.crop_size == mine.image_processor.crop_size
+
+
+def test_deepcopy_and_pickle_drop_the_native_handle():
+    """copy.deepcopy / pickle of a tower must not touch the ctypes context: the copy re-packs on first use."""
+    import copy
+    import pickle
+    t = fv.MobileCLIPVisionTower("mobileclip_l_256", ARGS)
+    t._ctx, t._ctx_key, t._dirty = object(), (0, 256), False           # stands for a live handle (no GPU in this test)
+    c = copy.deepcopy(t)
+    assert c._ctx is None and c._dirty is True and c is not t
+    assert all(torch.equal(a, b) for a, b in zip(c.state_dict().values(), t.state_dict().values()))
+    c._dirty = False
+    c.vision_tower.model.load_state_dict(t.vision_tower.model.state_dict(), strict=True)
+    assert c._dirty is True and t._dirty is False, "the copy's load_state_dict hooks must mark the COPY dirty"
+    t._ctx = None
+    p = pickle.loads(pickle.dumps(t))
+    assert p._ctx is None and p._dirty is True and p.input_image_size == 256
+
+
+def test_misshaped_inputs_are_rejected_before_the_library_sees_them():
+    """encode_images routes tensors through encode_images_with_projector: both entry points validate shape first."""
+    t = fv.MobileCLIPVisionTower("mobileclip_l_256", ARGS)
+    proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=64))
+    for bad in (torch.zeros(1, 3, 128, 128), torch.zeros(1, 4, 256, 256), torch.zeros(3, 256, 256), torch.zeros(0, 3, 256, 256)):
+        with pytest.raises(ValueError, match="expected images of shape"):
+            t._check_images(bad)
+        with pytest.raises(ValueError, match="expected images of shape"):
+            t.encode_images_with_projector(bad, proj)
+    wrong = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=1024, hidden_size=64))
+    with pytest.raises(ValueError, match="mlp2x_gelu projector must be"):
+        t.encode_images_with_projector(torch.zeros(1, 3, 256, 256), wrong)
