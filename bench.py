@@ -91,26 +91,28 @@ def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True):
 
 
 def pmc_traffic(kernel_class: str):
-    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (`profiles/*_pmc_summary.json`,
-    collected with separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B read requests at 64 B).  None if no such profile is in the tree."""
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (`profiles/*_pmc_summary.json`, written by
+    tools/run_pmc.sh + tools/pmc_summary.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 tallies 128-B read requests at 64 B).  The summary is keyed by kernel
+    CLASS (regular expressions on the kernel names, tools/pmc_summary.py), not by mangled instantiation names.  None if the newest
+    summary has no such class."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))]
     if not files:
         return None, None
     prof = json.load(open(files[-1]))
-    parts = {"ffn_fused": [("ffn_fused_kernelILi384E", 24), ("ffn_fused_kernelILi192E", 12), ("ffn_fused_kernelILi96E", 2)],
-             "dw7": [("dwconv_tiled_kernelILi7ELi1ELi1ELb0ELi64E", 44), ("dwconv_tiled_kernelILi7ELi1ELi1ELb0ELi32E", 2)],
-             "dw3": [("dwconv_tiled_kernelILi3ELi1ELi1ELb0ELi64E", 36), ("dwconv_tiled_kernelILi3ELi1ELi1ELb0ELi32E", 2)]}.get(kernel_class)
+    parts = {"ffn_fused": ["ffn_fused_c384", "ffn_fused_c192", "ffn_fused_c96"], "dw7": ["dw7_s1"], "dw3": ["dw3_s1"],
+             "attention": ["attention"], "dw_down": ["dw_down"]}.get(kernel_class)
     if not parts:
         return None, None
     tot, n = 0.0, 0
-    for sub, launches in parts:
-        hit = [v for k, v in prof.items() if sub in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
-        if not hit:
+    for cls in parts:
+        c = prof.get(cls)
+        if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             return None, None
-        tot += launches * 1024.0 * (2.0 * hit[0]["FETCH_SIZE"]["per_dispatch"] + hit[0]["WRITE_SIZE"]["per_dispatch"])
-        n += launches
+        d = c["FETCH_SIZE"]["dispatches"]
+        tot += d * 1024.0 * (2.0 * c["FETCH_SIZE"]["per_dispatch"] + c["WRITE_SIZE"]["per_dispatch"])
+        n += d
     return tot / n, os.path.relpath(files[-1], ROOT)
 
 

@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 evidence for one round, to be run ON THE GPU BOX (through gpurun) from the repo root:
+#     bash tools/run_pmc.sh r02            -> gpurun_out/r02_{trace,fetch,write,sq,grbm}/*_results.db
+# then (anywhere):  python tools/pmc_summary.py r02 gpurun_out/r02_* > profiles/r02_pmc_summary.md   (+ .json next to it)
+# Separate passes per MI355X_MICROARCH.md "rocprofv3 PMC slots" (FETCH_SIZE = 3 TCC slots, WRITE_SIZE = 2: not in one pass);
+# --kernel-trace only beside --pmc (gpurun refuses sys/runtime traces with counters).  One launch at a time: FVHD_DUAL=0.
+set -u
+TAG=${1:-r02}
+export FVHD_DUAL=0 TMPDIR=/tmp
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+mkdir -p gpurun_out
+run() { # name, extra rocprofv3 args...
+    local name=$1; shift
+    timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_${name} -o ${name} "$@" -- $CMD > gpurun_out/${TAG}_${name}.log 2>&1
+    echo "${name}: rc=$? $(ls gpurun_out/${TAG}_${name} 2>/dev/null | head -3 | tr '\n' ' ')"
+}
+run trace
+run fetch --pmc FETCH_SIZE
+run write --pmc WRITE_SIZE
+run sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS
+run grbm --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
