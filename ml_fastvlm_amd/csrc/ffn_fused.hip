@@ -360,9 +360,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     u32x4 xq[CIO ? NL : 1];
     bf16x4 xres[NB][NFR][4];
     if constexpr (CIO) {
+        int xln = lane;
+        asm volatile("" : "+v"(xln));
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const size_t gb = tile_b + (size_t)(i * 64 + lane) * 16;
+            const size_t gb = tile_b + (size_t)(i * 64 + xln) * 16;
             xq[i] = *(const u32x4*)((const char*)X + (gb < last_b ? gb : last_b));
         }
     } else {
@@ -386,14 +388,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     // X: coalesced registers -> LDS -> MFMA layout;  x + ls * (o + b2) in fp32, ONE rounding to bf16 -> LDS -> coalesced store.
     if constexpr (CIO) {
     __syncthreads();                         // all waves are done reading the weight rings
+    // per-lane offsets of the epilogue from an OPAQUE copy of the lane id: otherwise LLVM hoists ~40 address registers above the
+    // chunk loop and spills accumulators around them (116 B of scratch per lane at C = 192: +117 MB of HBM writes per launch in
+    // the PMC pass of profiles/r02a)
+    int eln = lane;
+    asm volatile("" : "+v"(eln));
+    const int eli = eln & 31, ehalf = eln >> 5;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) *(u32x4*)(stage + ffn_slot_of<C>(i * 64 + lane)) = xq[i];
+    for (int i = 0; i < NL; ++i) *(u32x4*)(stage + ffn_slot_of<C>(i * 64 + eln)) = xq[i];
 #pragma unroll
     for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n0 = nf * 32 + 8 * q + 4 * half;
-            char* slot = stage + ffn_slot_of<C>(li * CPR + nf * 4 + q) + half * 8;
+            const int n0 = nf * 32 + 8 * q + 4 * ehalf;
+            char* slot = stage + ffn_slot_of<C>(eli * CPR + nf * 4 + q) + ehalf * 8;
             const f32x4 bv = *(const f32x4*)(b2 + n0), lv = *(const f32x4*)(ls + n0);
             const f32x4 rv = bf4_to_f32(*(const bf16x4*)slot);
             f32x4 v;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     const int rows_ok = M - row0;            // rows of this tile that exist
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const int id = i * 64 + lane;
+        const int id = i * 64 + eln;
         const u32x4 v = *(const u32x4*)(stage + ffn_slot_of<C>(id));
         if (id < rows_ok * CPR) *(u32x4*)((char*)X + tile_b + (size_t)id * 16) = v;
     }
@@ -1083,6 +1091,8 @@ extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* 
 #endif
     if (C == 384) e = persist ? launch_ffn_persist4<384>(st, a, w1, w2, b1, b2, ls, x, M) : launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
     else if (C == 192) e = persist ? launch_ffn_persist8<192>(st, a, w1, w2, b1, b2, ls, x, M) : launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
-    else if (C == 96) e = persist ? launch_ffn_persist8<96>(st, a, w1, w2, b1, b2, ls, x, M) : launch_ffn<96, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
+    // C = 96: 152 registers since the epilogue offsets stopped being hoisted -> three workgroups (waves) per SIMD: the kernel is
+    // VALU-issue-bound (16 GELUs per 12 MFMAs), a third instruction stream per SIMD is what it needs
+    else if (C == 96) e = persist ? launch_ffn_persist8<96>(st, a, w1, w2, b1, b2, ls, x, M) : launch_ffn<96, 1, 4, 0, 3, 3>(st, a, w1, w2, b1, b2, ls, x, M);
     return (int)e;
 }

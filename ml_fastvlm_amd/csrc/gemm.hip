@@ -21,8 +21,8 @@
 //     columns* of one output row (C/D layout: col = lane&15 -> m, row = 4*(lane>>4)+reg -> n).
 //     bias / layer-scale are then float4 loads, the residual and the store are 8-B bf16x4 accesses,
 //     and bias+GELU / bias+layer_scale+residual run in fp32 on the accumulators (one rounding, on store).
-//   * block ids are remapped so each XCD's private L2 sees a contiguous range of tiles (n fastest):
-//     the N/BN tiles that share an A panel run back-to-back on the same L2.
+//   * block ids are remapped so each XCD's private L2 sees a contiguous range of the tile order, and the order walks
+//     8 x 8 super-tiles (see the kernel): every A / W panel fetched from HBM feeds 8 resident tiles.
 #include "fvhd_common.h"
 
 #define EPI_NONE 0
@@ -54,8 +54,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, g = lane >> 4;
+    // Tile order.  Each XCD (private 4-MB L2) gets a contiguous range of the logical order (xcd_remap), and the logical order
+    // walks SUPER-TILES of up to 8 (N) x 8 (M) tiles: the ~64 workgroups resident on an XCD then share 8 A panels and 8 W
+    // panels, i.e. every panel byte fetched from HBM feeds 8 tiles.  Round 1 walked all tiles_n tiles of an M row first: at
+    // N = 2304 / 3072 the whole weight matrix (3.5 / 4.7 MB) cycled through the 4-MB L2 once per M row and the stage-3/4 GEMMs
+    // were fabric-bound (rocprofv3 FETCH_SIZE: 573 MB per qkv launch against 54 MB of operands, 5 TB/s - profiles/r02a).
     const int L = xcd_remap(blockIdx.x, nwg);
-    const int tm = L / tiles_n, tn = L - tm * tiles_n;
+    constexpr int GN = 8;
+    const int tiles_m = nwg / tiles_n;
+    const int grp = L / (tiles_m * GN), rem = L - grp * tiles_m * GN;
+    const int wg = min(GN, tiles_n - grp * GN);          // width of this N group (the last one may be narrower)
+    const int tm = rem / wg, tn = grp * GN + (rem - tm * wg);
     const int m0 = tm * BM, n0 = tn * BN;
 
     u32x4 ra[A_CH], rw[W_CH];

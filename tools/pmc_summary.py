@@ -7,8 +7,8 @@ Kernels are grouped by class (the classes of `fvhd_profile_read` / bench.py's `k
 fused ConvFFN and the depthwise kernels) with a regular expression on the demangled or mangled name, NOT by exact instantiation,
 so a re-tuned template parameter does not orphan the evidence ("What's weak" 7).
 HBM bytes: read = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md "HBM"), write = WRITE_SIZE x 1024.
-MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE-derived cycles of the dispatch) when GRBM_GUI_ACTIVE is present,
-else / (1024 x duration x 2.0 GHz)."""
+MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE-derived cycles of the dispatch) when GRBM_GUI_ACTIVE is present
+(the counter is summed over the 8 XCD instances: / 8), else / (1024 x duration x 2.0 GHz)."""
 import glob
 import json
 import os
@@ -85,9 +85,9 @@ def main():
         us = c["_trace"]["avg_us"] if "_trace" in c else next(iter(c.values()))["avg_us"]
         rd = 2 * g("FETCH_SIZE") * 1024 / 1e6 if g("FETCH_SIZE") is not None else None
         wr = g("WRITE_SIZE") * 1024 / 1e6 if g("WRITE_SIZE") is not None else None
-        gbs = (rd + wr) / us * 1e3 / 1e3 if rd is not None and wr is not None else None
-        gui = g("GRBM_GUI_ACTIVE")
-        clk = gui / (c["GRBM_GUI_ACTIVE"]["avg_us"] * 1e3) if gui else None         # cycles per ns
+        gbs = (rd + wr) / us * 1e3 if rd is not None and wr is not None else None      # MB / us = TB/s
+        gui = g("GRBM_GUI_ACTIVE")                                                         # summed over the 8 XCD instances
+        clk = gui / 8.0 / (c["GRBM_GUI_ACTIVE"]["avg_us"] * 1e3) if gui else None         # cycles per ns
         mf = g("SQ_VALU_MFMA_BUSY_CYCLES")
         busy = None
         if mf is not None:

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 evidence for one round, to be run ON THE GPU BOX (through gpurun) from the repo root:
 #     bash tools/run_pmc.sh r02            -> gpurun_out/r02_{trace,fetch,write,sq,grbm}/*_results.db
-# then (anywhere):  python tools/pmc_summary.py r02 gpurun_out/r02_* > profiles/r02_pmc_summary.md   (+ .json next to it)
+# The databases (~75 MB) stay on the box (gpurun merges at most 64 MiB back): they are summarised there into
+#     gpurun_out/r02_pmc_summary.{md,json} and gpurun_out/r02_kernel_trace_stats_single_stream.md  -> copy those into profiles/.
 # Separate passes per MI355X_MICROARCH.md "rocprofv3 PMC slots" (FETCH_SIZE = 3 TCC slots, WRITE_SIZE = 2: not in one pass);
 # --kernel-trace only beside --pmc (gpurun refuses sys/runtime traces with counters).  One launch at a time: FVHD_DUAL=0.
 set -u
@@ -19,3 +20,7 @@ run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS
 run grbm --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+python tools/pmc_summary.py ${TAG} gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_sq gpurun_out/${TAG}_grbm > gpurun_out/${TAG}_pmc_summary.md
+cp profiles/${TAG}_pmc_summary.json gpurun_out/ 2>/dev/null
+python tools/rocpd_summary.py gpurun_out/${TAG}_trace/trace_results.db > gpurun_out/${TAG}_kernel_trace_stats_single_stream.md
+rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_sq gpurun_out/${TAG}_grbm
