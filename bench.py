@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tower-only", action="store_true", help="time the vision tower without the projector")
+    ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives, barriers) even at WORLD_SIZE = 1")
+    ap.add_argument("--ttft", action="store_true", help="report time-to-first-token of FastVLM prefill instead (tools/ttft.py, BASELINE configs[2])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,7 +184,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    multi = world > 1 or (args.force_dist and "RANK" in os.environ)      # the distributed code path (also at world 1 when forced)
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -205,28 +208,39 @@ def main():
     def local_step():
         return tower(images) if args.tower_only else fv.encode_images(tower, proj, images)
 
+    side = D.gather_side(Hd)                     # 0.5B / 1.5B: gather the projected tokens; 7B (H = 3584 > 3072): gather before the projector
+
+    def _all_gather(t):                          # all_gather_tokens short-cuts world 1; the forced path still issues the collective
+        if world == 1:
+            out = torch.empty_like(t)
+            dist.all_gather_into_tensor(out, t.contiguous())
+            return out
+        return D.all_gather_tokens(t, B * world)
+
+    @torch.no_grad()
     def step():
-        local = local_step()
-        if world > 1:
-            return D.all_gather_tokens(local, B * world)
-        return local
+        if not multi:
+            return local_step()
+        if args.tower_only or side == "after":
+            return _all_gather(local_step())
+        return proj(_all_gather(tower(images)))
 
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out.float()).all()
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -241,9 +255,10 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{1 if R == 1024 else 4 if R == 1536 else '-'}]: FastViTHD encoder{'' if args.tower_only else ' + mlp2x_gelu projector (H=%d)' % Hd}, "
                                f"batch={B}/GPU synthetic {R}x{R} bf16 images in [0,1), seeded synthetic weights, "
-                               f"{'tokens all-gathered over RCCL at the projector boundary' if world > 1 else 'single GPU'}",
+                               f"{('tokens all-gathered over RCCL ' + side + ' the projector') if multi else 'single GPU'}",
                    "global_batch": B * world, "image_size": R, "tokens_per_image": (R // 64) ** 2, "parallelism": f"dp{world}",
-                   "hip_graph": bool(args.graph), "attention_operands": "e4m3" if args.attn_fp8 else "bf16"},
+                   "hip_graph": bool(args.graph), "attention_operands": "e4m3" if args.attn_fp8 else "bf16",
+                   **({"collective": f"all_gather_into_tensor over nccl (RCCL), world {world}", "gather_side": side} if multi else {})},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -294,7 +309,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

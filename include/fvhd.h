@@ -166,6 +166,19 @@ int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* hos
 int fvhd_op_ffn_fused(fvhd_stream_t stream, const void* A, const void* w1img, const float* b1, const void* w2img,
                       const float* b2, const float* ls, void* X, int M, int C);
 
+/* ---- multimodal embedding splice --------------------------------------------------
+ * The data movement of LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal (llava_arch.py:233-332) as one gather:
+ * out[b, t] = embedding-table row of a text token, a row of the image features, or zeros (padding), plus attention mask,
+ * position ids and labels of that position.  The host side (ml_fastvlm_amd/splice.py: splice_plan) supplies, per input
+ * position [B, L]: `start` = first output position of the token inside its spliced sequence (non-decreasing; dropped
+ * positions carry their successor's value), `feat_row0` = first row of the image in `feats` for a -200 token, -1 for text;
+ * `seqlen[b]` = length of the spliced (and truncated) sequence.  table [vocab, H], feats [n_feat_rows, H], out
+ * [B, max_len, H] of `dtype`; mask_out (uint8), pos_out, labels_out (int64) [B, max_len], labels_in [B, L], each may be NULL.
+ * left_pad != 0 = tokenizer_padding_side "left" (llava_arch.py:306).  All pointers are device pointers. */
+int fvhd_op_splice(fvhd_stream_t stream, const int64_t* ids, const int32_t* start, const int32_t* seqlen, const int64_t* feat_row0,
+                   const int64_t* labels_in, const void* table, const void* feats, void* out, uint8_t* mask_out, int64_t* pos_out,
+                   int64_t* labels_out, int B, int L, int H, int max_len, int64_t vocab, int64_t n_feat_rows, int left_pad, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

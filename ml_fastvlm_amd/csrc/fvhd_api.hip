@@ -26,6 +26,8 @@ int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, 
 int fvhd_launch_cast_to_bf16(hipStream_t, const void*, int, void*, long);
 int fvhd_launch_ffn_fused(hipStream_t, const void*, const void*, const float*, const void*, const float*, const float*, void*, int, int);
 int fvhd_ffn_fused_supported(int);
+int fvhd_launch_splice(hipStream_t, const long*, const int*, const int*, const long*, const long*, const void*, const void*, void*,
+                       unsigned char*, long*, long*, int, int, int, int, long, long, int, int);
 int fvhd_ffn_pack_host(int, const float*, const float*, uint16_t*, uint16_t*);
 }
 
@@ -979,6 +981,17 @@ int fvhd_op_ffn_fused(fvhd_stream_t st, const void* A, const void* w1img, const 
 {
     int e = fvhd_launch_ffn_fused((hipStream_t)st, A, w1img, b1, w2img, b2, ls, X, M, C);
     return e ? hip_fail("fvhd_op_ffn_fused", (hipError_t)e) : 0;
+}
+
+int fvhd_op_splice(fvhd_stream_t st, const int64_t* ids, const int32_t* start, const int32_t* seqlen, const int64_t* feat_row0,
+                   const int64_t* labels_in, const void* table, const void* feats, void* out, uint8_t* mask_out, int64_t* pos_out,
+                   int64_t* labels_out, int B, int L, int H, int max_len, int64_t vocab, int64_t n_feat_rows, int left_pad, int dtype)
+{
+    if (!ids || !start || !seqlen || !feat_row0 || !table || !feats || !out) return fail("fvhd_op_splice: NULL argument");
+    if (dtype < 0 || dtype > 2) return fail("fvhd_op_splice: bad dtype");
+    int e = fvhd_launch_splice((hipStream_t)st, (const long*)ids, start, seqlen, (const long*)feat_row0, (const long*)labels_in, table, feats,
+                               out, mask_out, (long*)pos_out, (long*)labels_out, B, L, H, max_len, (long)vocab, (long)n_feat_rows, left_pad, dtype);
+    return e ? hip_fail("fvhd_op_splice", (hipError_t)e) : 0;
 }
 
 int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img)

@@ -40,6 +40,12 @@ def _worker(rank, world, port, global_batch, q):
         loc = D.encode_images_data_parallel(_fake_encode, local, global_batch, gather=False)
         lo, hi = D.shard_bounds(global_batch, rank, world)
         ok = ok and torch.equal(loc, want[lo:hi])
+        # gather before / after the projector (FastVLM-7B vs 0.5B): same result, only the message width differs
+        proj = lambda t: t * 2.0 + 1.0
+        for hidden, side in ((896, "after"), (3584, "before")):
+            assert D.gather_side(hidden) == side
+            got = D.encode_images_sharded(_fake_encode, proj, local, global_batch, hidden)
+            ok = ok and torch.equal(got, proj(want))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

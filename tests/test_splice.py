@@ -1,0 +1,157 @@
+"""Embedding splice: oracle restatement pinned against the reference METHOD (live, when mounted); the product's
+plan (batched integer ops) checked against the oracle on CPU through a torch gather; the HIP kernel against the oracle on the GPU."""
+import random
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from ml_fastvlm_amd import splice as S
+from oracle import ref_import
+from oracle import splice_oracle as O
+
+
+def _case(seed, B=4, L=24, H=64, V=97, T=(16,), with_mask=True, with_labels=True, empty_sample=False):
+    g = torch.Generator().manual_seed(seed)
+    rnd = random.Random(seed)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    mask = torch.ones(B, L, dtype=torch.long)
+    n_feats = 0
+    for b in range(B):
+        n_img = rnd.choice([0, 1, 1, 2, 3])
+        for p in rnd.sample(range(L), n_img):
+            ids[b, p] = S.IMAGE_TOKEN_INDEX
+        if with_mask:
+            pad = rnd.randrange(0, L // 2)
+            if rnd.random() < 0.5:
+                mask[b, L - pad:] = 0           # right padding ...
+            else:
+                mask[b, :pad] = 0               # ... or left padding (drops whatever was there, image tokens included)
+        if empty_sample and b == 1:
+            mask[b] = 0
+        kept = ids[b][mask[b].bool()]
+        n_feats += max(1, int((kept == S.IMAGE_TOKEN_INDEX).sum()))
+    feats = [torch.randn(rnd.choice(T), H, generator=g) for _ in range(n_feats + 1)]     # one spare entry
+    labels = torch.randint(0, V, (B, L), generator=g) if with_labels else None
+    W = torch.randn(V, H, generator=g)
+    return ids, (mask if with_mask else None), labels, feats, W
+
+
+def _run_plan_on_cpu(ids, mask, labels, feats, W, side, max_length):
+    """the product's index plan + a torch gather standing in for the HIP kernel (same row semantics as csrc/splice.hip)"""
+    flat, lens = S.flatten_features(feats)
+    start, seqlen, row0, keep, max_len = S.splice_plan(ids, mask, lens, max_length)
+    B, L = ids.shape
+    out = torch.zeros(B, max_len, W.shape[1])
+    am = torch.zeros(B, max_len, dtype=torch.bool)
+    pos = torch.zeros(B, max_len, dtype=torch.long)
+    lab = torch.full((B, max_len), S.IGNORE_INDEX, dtype=torch.long)
+    for b in range(B):
+        n = int(seqlen[b])
+        shift = max_len - n if side == "left" else 0
+        for u in range(n):
+            j = int((start[b] <= u).nonzero().max())          # last position whose start <= u: what the kernel's binary search finds
+            t = u + shift
+            if row0[b, j] >= 0:
+                out[b, t] = flat[int(row0[b, j]) + u - int(start[b, j])]
+            else:
+                out[b, t] = W[ids[b, j]]
+                if labels is not None:
+                    lab[b, t] = labels[b, j]
+            am[b, t], pos[b, t] = True, u
+    return out, am, pos, lab, max_len
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_plan_matches_oracle_on_cpu(seed):
+    rnd = random.Random(100 + seed)
+    side = rnd.choice(["right", "left"])
+    max_length = rnd.choice([None, None, 20, 33])
+    ids, mask, labels, feats, W = _case(seed, T=rnd.choice([(16,), (5, 9, 16)]), with_mask=seed % 3 != 0, with_labels=seed % 2 == 0,
+                                        empty_sample=seed == 7)
+    want = O.splice(ids, None, mask, labels, feats, W, side, max_length)
+    out, am, pos, lab, max_len = _run_plan_on_cpu(ids, mask, labels, feats, W, side, max_length)
+    assert out.shape == want[4].shape and torch.equal(out, want[4])
+    full = O.splice(ids, torch.zeros(1, dtype=torch.long), torch.ones_like(ids) if mask is None else mask,
+                    labels if labels is not None else torch.full_like(ids, 5), feats, W, side, max_length)
+    assert torch.equal(am, full[2].bool()) and torch.equal(pos, full[1])
+    if labels is not None:
+        assert torch.equal(lab, want[5])
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="reference tree not mounted")
+@pytest.mark.parametrize("seed", range(10))
+def test_oracle_matches_the_reference_method(seed):
+    ref_import.import_reference()
+    from llava.model.llava_arch import LlavaMetaForCausalLM
+    rnd = random.Random(seed)
+    side = rnd.choice(["right", "left"])
+    max_length = rnd.choice([None, 18, 40])
+    ids, mask, labels, feats, W = _case(seed, T=(16,) if seed % 2 else (5, 9, 16), with_mask=seed % 3 != 0, with_labels=seed % 2 == 0)
+    emb = torch.nn.Embedding.from_pretrained(W)
+    same_T = len({f.shape[0] for f in feats}) == 1
+
+    class Fake:
+        config = SimpleNamespace(tokenizer_padding_side=side, tokenizer_model_max_length=max_length, mm_patch_merge_type="flat")
+        device = torch.device("cpu")
+
+        def get_vision_tower(self):
+            return object()
+
+        def get_model(self):
+            return SimpleNamespace(embed_tokens=emb)
+
+        def encode_images(self, images):      # `images` is only a carrier here: the features are precomputed
+            return torch.stack(feats, 0) if same_T else torch.cat(feats, 0)
+
+    fake = Fake()
+    if same_T:
+        images = torch.zeros(len(feats), 3, 2, 2)                         # tensor path (llava_arch.py:209-210)
+    else:
+        images = [torch.zeros(f.shape[0], 3, 2, 2) for f in feats]        # list path: split sizes = rows per image, 'flat' merge (:154-164)
+        Fake.encode_images = lambda self, cat: torch.cat(feats, 0).reshape(-1, 1, W.shape[1])
+    pos_in = None if seed % 4 else torch.arange(ids.shape[1])
+    got_ref = LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal(fake, ids, pos_in, mask, None, labels, images)
+    want = O.splice(ids, pos_in, mask, labels, feats, W, side, max_length)
+    for a, b, name in zip(got_ref, want, ("input_ids", "position_ids", "attention_mask", "past", "embeds", "labels")):
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert a.dtype == b.dtype and torch.equal(a, b), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("seed", [0, 3, 7])
+def test_hip_splice_matches_oracle(seed, dtype):
+    side = "left" if seed % 2 else "right"
+    max_length = None if seed != 3 else 40
+    ids, mask, labels, feats, W = _case(seed, B=5, L=40, H=896, V=1000, T=(16,) if seed else (7, 16, 33), empty_sample=seed == 7)
+    W, feats = W.to(dtype), [f.to(dtype) for f in feats]
+    want = O.splice(ids, torch.arange(ids.shape[1]), mask, labels, feats, W, side, max_length)
+    got = S.multimodal_splice(ids.cuda(), torch.arange(ids.shape[1]).cuda(), mask.cuda(), labels.cuda(), [f.cuda() for f in feats],
+                              W.cuda(), side, max_length)
+    torch.cuda.synchronize()
+    assert got[0] is None and got[3] is None
+    for a, b, name in ((got[4], want[4], "embeds"), (got[1], want[1], "position_ids"), (got[2], want[2], "attention_mask"), (got[5], want[5], "labels")):
+        assert a.dtype == b.dtype and torch.equal(a.cpu(), b), name
+    none = S.multimodal_splice(ids.cuda(), None, None, None, torch.stack(feats, 0).cuda() if seed else [f.cuda() for f in feats], W.cuda(), side)
+    assert none[1] is None and none[2] is None and none[5] is None
+
+
+@pytest.mark.gpu
+def test_hip_splice_prefill_shape_b8():
+    """BASELINE.json configs[2] shape: 8 sequences of ~30 text tokens + one 256-token image each, H = 896, bf16."""
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 151936, (8, 30), generator=g)
+    ids[:, 14] = S.IMAGE_TOKEN_INDEX
+    feats = torch.randn(8, 256, 896, generator=g).to(torch.bfloat16)
+    W = torch.randn(151936, 896, generator=g).to(torch.bfloat16)
+    want = O.splice(ids, None, None, None, [f for f in feats], W)
+    got = S.multimodal_splice(ids.cuda(), None, None, None, feats.cuda(), W.cuda())
+    assert got[4].shape == (8, 285, 896) and torch.equal(got[4].cpu(), want[4])
+
+
+def test_no_cpu_path():
+    ids, mask, labels, feats, W = _case(0)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        S.multimodal_splice(ids, None, mask, labels, feats, W)
