@@ -175,6 +175,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives, barriers) even at WORLD_SIZE = 1")
     ap.add_argument("--ttft", action="store_true", help="report time-to-first-token of FastVLM prefill instead (tools/ttft.py, BASELINE configs[2])")
     args = ap.parse_args()
+    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
+
+    t_start = time.perf_counter()
+
+    def trace(msg):                              # FVHD_BENCH_TRACE=1: where the wall time of a run goes (stderr)
+        if os.environ.get("FVHD_BENCH_TRACE") == "1":
+            print(f"[bench {time.perf_counter() - t_start:8.2f}s] {msg}", file=sys.stderr, flush=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -187,12 +194,27 @@ def main():
     multi = world > 1 or (args.force_dist and "RANK" in os.environ)      # the distributed code path (also at world 1 when forced)
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        trace("init_process_group ...")
         dist.init_process_group("nccl", device_id=dev)
+        trace("process group up")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import ml_fastvlm_amd as fv
     from ml_fastvlm_amd import distributed as D
     from ml_fastvlm_amd import synth
+
+    if args.ttft:                                # BASELINE.json configs[2]: a latency metric, its own JSON line (tools/ttft.py)
+        assert world == 1, "--ttft is a single-GPU latency measurement"
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import ttft
+        Bt = args.batch if args.batch_given else 8
+        r = ttft.measure(Bt, args.res, args.hidden, args.steps, args.warmup, dev, args.graph)
+        print(json.dumps({"metric": f"TTFT FastVLM prefill, batch={Bt} @{args.res}x{args.res} bf16", "value": r["ttft_ms_median"], "unit": "ms",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ttft_ms_median"], "higher_is_better": False,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "BASELINE.json configs[2]: encode_images -> embedding splice -> Qwen2 prefill -> first token, "
+                                                 "qwen_2 prompt around one <image>, synthetic ids/images, random weights", **r}}))
+        return
 
     B, R, Hd = args.batch, args.res, args.hidden
     tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{R}", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_hip_graph=args.graph,
@@ -201,6 +223,7 @@ def main():
     proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=Hd))
     proj.load_state_dict(synth.synthetic_projector_state_dict(Hd, 1234), strict=True)
     tower, proj = tower.to(dev, torch.bfloat16), proj.to(dev, torch.bfloat16)
+    trace("tower + projector built")
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     images = torch.rand((B, 3, R, R), generator=g).to(dev, torch.bfloat16)      # synthetic, in [0,1), HBM-resident
 
@@ -228,6 +251,7 @@ def main():
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
+    trace("warm-up done")
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -239,6 +263,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    trace("timed region done")
     assert torch.isfinite(out.float()).all()
     if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -310,7 +335,9 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if multi:
+        trace("destroy_process_group ...")
         dist.destroy_process_group()
+    trace("done")
 
 
 if __name__ == "__main__":

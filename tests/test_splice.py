@@ -134,7 +134,8 @@ def test_hip_splice_matches_oracle(seed, dtype):
     assert got[0] is None and got[3] is None
     for a, b, name in ((got[4], want[4], "embeds"), (got[1], want[1], "position_ids"), (got[2], want[2], "attention_mask"), (got[5], want[5], "labels")):
         assert a.dtype == b.dtype and torch.equal(a.cpu(), b), name
-    none = S.multimodal_splice(ids.cuda(), None, None, None, torch.stack(feats, 0).cuda() if seed else [f.cuda() for f in feats], W.cuda(), side)
+    more = feats * 3        # without the mask every -200 is live: more feature entries are consumed
+    none = S.multimodal_splice(ids.cuda(), None, None, None, torch.stack(more, 0).cuda() if seed else [f.cuda() for f in more], W.cuda(), side)
     assert none[1] is None and none[2] is None and none[5] is None
 
 

@@ -1,0 +1,103 @@
+"""Time-to-first-token of FastVLM prefill on one MI355X (BASELINE.json configs[2]; `python bench.py --ttft` calls `measure`).
+
+TTFT as the reference's app defines it (`app/FastVLM App/FastVLMModel.swift:113-138`): wall time from the start of the image path
+to the first generated token, here for a batch of B prompts:
+
+    encode_images (FastViTHD + mlp2x_gelu, libfvhd)  ->  embedding splice (fvhd_op_splice, llava_arch.py:233-332)
+    ->  Qwen2 prefill on `inputs_embeds` (stock `transformers` Qwen2ForCausalLM on PyTorch-ROCm, llava_qwen.py:92-103,138-143)
+    ->  argmax of the last position's logits = first token  ->  host sync.
+
+The LLM is third-party arithmetic: the stock HF module with the Qwen2-0.5B / -7B architecture and random weights
+(no checkpoints on this box), bf16, SDPA attention.  The prompt is the `qwen_2` conversation (`llava/conversation.py:407-415`) around
+one <image>: 14 text tokens, the image, 10 text tokens - synthetic token ids, because no tokenizer files are available offline."""
+from __future__ import annotations
+
+import time
+from types import SimpleNamespace
+
+import torch
+
+QWEN2 = {   # published architectures (Qwen2 model cards); hidden size selects the entry
+    896: dict(hidden_size=896, intermediate_size=4864, num_hidden_layers=24, num_attention_heads=14, num_key_value_heads=2, tie_word_embeddings=True, vocab_size=151936),
+    1536: dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2, tie_word_embeddings=True, vocab_size=151936),
+    3584: dict(hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4, tie_word_embeddings=False, vocab_size=152064),
+}
+PROMPT_BEFORE, PROMPT_AFTER = 14, 10      # "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n" | "\nDescribe the image.<|im_end|>\n<|im_start|>assistant\n"
+
+
+def build_llm(hidden: int, dev):
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    cfg = Qwen2Config(max_position_embeddings=32768, rope_theta=1e6, rms_norm_eps=1e-6, **QWEN2[hidden])
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(7)
+    with torch.device(dev):
+        llm = Qwen2ForCausalLM(cfg).to(torch.bfloat16)
+    return llm.eval()
+
+
+@torch.no_grad()
+def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, graph: bool = False):
+    import ml_fastvlm_amd as fv
+    from ml_fastvlm_amd import splice as S
+    from ml_fastvlm_amd import synth
+
+    tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{res}", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_hip_graph=graph))
+    tower.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234, profile="mild"), strict=True)
+    proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=hidden))
+    proj.load_state_dict(synth.synthetic_projector_state_dict(hidden, 1234), strict=True)
+    tower, proj = tower.to(dev, torch.bfloat16), proj.to(dev, torch.bfloat16)
+    llm = build_llm(hidden, dev)
+    table = llm.get_input_embeddings().weight
+    g = torch.Generator().manual_seed(11)
+    images = torch.rand((batch, 3, res, res), generator=g).to(dev, torch.bfloat16)
+    ids = torch.randint(0, 151000, (batch, PROMPT_BEFORE + 1 + PROMPT_AFTER), generator=g)
+    ids[:, PROMPT_BEFORE] = S.IMAGE_TOKEN_INDEX
+    ids = ids.to(dev)
+    mask = torch.ones_like(ids)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def once():
+        ev[0].record()
+        feats = fv.encode_images(tower, proj, images)
+        ev[1].record()
+        _, pos, am, _, embeds, _ = S.multimodal_splice(ids, None, mask, None, feats, table)
+        ev[2].record()
+        out = llm(inputs_embeds=embeds, attention_mask=am, use_cache=True, logits_to_keep=1)
+        tok = out.logits[:, -1].argmax(-1)
+        ev[3].record()
+        return tok, embeds.shape[1]
+
+    for _ in range(max(1, warmup)):
+        tok, seq = once()
+    torch.cuda.synchronize()
+    wall, parts = [], []
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tok, seq = once()
+        first = tok.cpu()                              # the first token reaches the host: end of TTFT
+        wall.append(1e3 * (time.perf_counter() - t0))
+        parts.append([ev[i].elapsed_time(ev[i + 1]) for i in range(3)])
+    assert first.shape == (batch,)
+    wall.sort()
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    n_par = sum(p.numel() for p in llm.parameters())
+    return {"ttft_ms_median": round(wall[len(wall) // 2], 3), "ttft_ms_min": round(wall[0], 3), "ttft_ms_max": round(wall[-1], 3),
+            "encode_images_ms": round(med([p[0] for p in parts]), 3), "splice_ms": round(med([p[1] for p in parts]), 3),
+            "prefill_first_token_ms": round(med([p[2] for p in parts]), 3),
+            "batch": batch, "prompt_tokens": int(seq), "image_tokens": (res // 64) ** 2, "llm": f"Qwen2 architecture, hidden {hidden}, {n_par / 1e9:.2f} B parameters, random bf16 weights, stock transformers SDPA",
+            "steps": steps}
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--hidden", type=int, default=896)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.batch, a.res, a.hidden, a.steps, a.warmup, torch.device("cuda", 0), a.graph)))
