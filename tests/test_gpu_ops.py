@@ -235,6 +235,11 @@ def _pack_dw(w):   # [Cout,1,K,K] -> fp32 [K*K][Cout]
     (7, 2, 2, 1, 192, 40, 25),     # stride 2, odd width
     (3, 2, 1, 1, 96, 70, 66),      # stem[1]: 3 tiles in y
     (3, 1, 2, 0, 64, 20, 20),
+    (7, 1, 1, 0, 192, 40, 128),    # matrix-core dw7 (dwconv_mfma.hip): two strips, two row chunks (second ragged)
+    (7, 1, 1, 0, 128, 70, 96),     # ragged second strip (W = 64 + 32), three chunks
+    (7, 1, 1, 0, 64, 3, 64),       # fewer rows than taps
+    (7, 1, 1, 0, 384, 64, 64),     # stage 3 of the 1024^2 tower
+    (7, 1, 1, 0, 64, 33, 67),      # second strip 3 px wide
 ])
 def test_dwconv(K, S, mult, gelu, Cin, H, W):
     lib = _lib.load()

@@ -511,6 +511,185 @@ done:
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may be in flight when the LDS is released
 }
 
+
+// ---------------------------------------------------------------- 3d. workgroup-cooperative I/O
+// v3 moves 32-B segments (16 channels of one pixel) per lane pair: reads alone 5 TB/s, writes alone 4.5 TB/s, both together
+// 3.3 TB/s.  Here the 4 waves of a workgroup own 4 adjacent channel groups = 64 channels = one 128-B line per pixel: the
+// row segment is DMAed as whole lines into a raw ring SHARED by the workgroup (each wave issues 2 of the 8 interior 1-KiB
+// pieces and a quarter of the halo piece), each wave transposes its own 32-B column of every pixel, the finished output row
+// is assembled in a shared [px][64 ch] buffer and leaves as whole lines.  One s_barrier per row.
+template <int C, int RS, int ABL>
+__global__ __launch_bounds__(256, 2) void dw7_mfma_v4(const u16* __restrict__ x, u16* __restrict__ y, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, int B, int H, int W, int RC, int nstrip, int nchunk)
+{
+    constexpr int NT = 4, NW = 4, CW = 64, SW = 64, IWX = 72, NCB = C / CW;
+    constexpr int OPX = 144;                       // output staging: 128 B of channels + 16 B pad per pixel (4 px of a ds_write_b16 on 4 bank groups)
+    constexpr int RAWB = IWX * CW * 2, OB = SW * OPX, TBY = 16 * P * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* raw = smem;                                       // [RS][64 px interior | 8 px halo][64 ch]
+    char* O = smem + RS * RAWB;                             // [2][64 px][64 ch]
+    u16* T = (u16*)(smem + RS * RAWB + 2 * OB + wv * TBY);  // per wave [16 ch][P]
+    const int blk = lane >> 2, q = lane & 3;
+    int L = blockIdx.x;
+    if (!(ABL & 64)) { const int G = gridDim.x, per = G / 8; if (G % 8 == 0) L = (L % 8) * per + L / 8; }     // consecutive logical tiles share an XCD (L2): halo rows / columns
+    const int cb = L % NCB; L /= NCB;
+    const int strip = L % nstrip; L /= nstrip;
+    const int chunk = L % nchunk;
+    const int n = L / nchunk;
+    const int c0 = cb * CW + wv * 16, x0 = strip * SW, ylo = chunk * RC, yhi = min(H, ylo + RC);
+    const unsigned img_bytes = (unsigned)H * W * C * 2, row_bytes = (unsigned)W * C * 2;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)n * H * W * C), 0, img_bytes, 0x00020000);
+    const char* ximg = (const char*)(x + (size_t)n * H * W * C);
+
+    s16x4 bop[7][3];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kx = 4 * (s - 1) + k - q + 3;
+                const float v = (kx >= 0 && kx < 7) ? w[(size_t)(ky * 7 + kx) * C + c0 + blk] : 0.f;
+                bop[ky][s][k] = (short)d_f2bf(v);
+            }
+    const float bv = bias[c0 + blk];
+    f32x4 acc[7][NT];
+#pragma unroll
+    for (int sl = 0; sl < 7; ++sl)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[sl][t] = f32x4{bv, bv, bv, bv};
+
+    // ---- loads: interior pieces 2 wv and 2 wv + 1 (8 px x 128 B each), halo piece lanes 16 wv .. 16 wv + 15
+    // inside every 1-KiB piece the 16-B chunks are stored [consumer wave][px][half] (a wave's later ds_read_b128 of its 32-B column
+    // is then bank-conflict free): DMA lane l = (consumer l >> 4, px (l >> 1) & 7, half l & 1); the global side is still 8 whole lines
+    const unsigned vint = (unsigned)(((x0 + 16 * wv + ((lane >> 1) & 7)) * C + cb * CW) * 2 + (lane >> 4) * 32 + (lane & 1) * 16);
+    const unsigned vst = (unsigned)(((x0 + 16 * wv + (lane >> 3)) * C + cb * CW) * 2 + (lane & 7) * 16);
+    const int hp = lane >> 3, hx = hp < 4 ? x0 - 4 + hp : x0 + 60 + hp;
+    const unsigned vhalo = (unsigned)((min(max(hx, 0), W - 1) * C + cb * CW) * 2 + (lane & 7) * 16);      // halo piece: plain [px][128 B]
+    const unsigned long long hmask = 0xffffull << (16 * wv);
+    const unsigned raw_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)raw;
+    auto dma = [&](int r, int slot) {
+        const char* rb0 = ximg + (size_t)r * row_bytes;
+        const char* rb1 = rb0 + 8 * C * 2;
+        const unsigned d0 = raw_lds + slot * RAWB + 2048 * wv, dh = raw_lds + slot * RAWB + 8192;
+        unsigned keep; unsigned long long ex;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+                     "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+                     "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %8\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+                     "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex) : "v"(vint), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb0), "s"(rb1), "s"(hmask) : "memory", "scc");
+    };
+    // ---- transposition: this wave's 32-B column of the 72 pixels (T column 0..3 left halo, 4..67 interior, 68..71 right halo)
+    unsigned roff[3];
+    bool okm[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int col = 32 * m + (lane >> 1), xi = x0 - 4 + col;
+        okm[m] = col < IWX && xi >= 0 && xi < W;
+        const int cc = min(col, IWX - 1);
+        const int ip = cc - 4;                                    // interior pixel index
+        roff[m] = (unsigned)(cc < 4 ? 8192 + cc * 128 + wv * 32 + (lane & 1) * 16 : cc >= 68 ? 8192 + (cc - 64) * 128 + wv * 32 + (lane & 1) * 16
+                                    : (ip >> 3) * 1024 + wv * 256 + (ip & 7) * 32 + (lane & 1) * 16);
+    }
+    typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+    auto transpose = [&](int slot) {
+        if (ABL & 4) return;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            if (m == 2 && lane >= 16) continue;
+            const u32x4 v = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
+            if (okm[m]) {
+                u16* d = T + (8 * (lane & 1)) * P + 32 * m + (lane >> 1);
+                d[0 * P] = (u16)v.x; d[1 * P] = (u16)(v.x >> 16);
+                d[2 * P] = (u16)v.y; d[3 * P] = (u16)(v.y >> 16);
+                d[4 * P] = (u16)v.z; d[5 * P] = (u16)(v.z >> 16);
+                d[6 * P] = (u16)v.w; d[7 * P] = (u16)(v.w >> 16);
+            }
+        }
+    };
+    {
+        f32x4 z = {0, 0, 0, 0};
+        for (int i = lane; i < TBY / 16; i += 64) *(f32x4*)((char*)T + i * 16) = z;
+    }
+    // ---- output: own 16 channels into the shared row buffer, then pieces 2 wv, 2 wv + 1 as whole lines
+    auto stage = [&](f32x4 (&a)[NT], int ob) {
+        if (!(ABL & 2)) {
+            u16* Ow = (u16*)(O + ob * OB + q * OPX + wv * 32 + blk * 2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a[t][0], a[t][1]}, bf16x2_t));
+                const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a[t][2], a[t][3]}, bf16x2_t));
+                Ow[(16 * t + 0) * (OPX / 2)] = (u16)p01; Ow[(16 * t + 4) * (OPX / 2)] = (u16)(p01 >> 16);
+                Ow[(16 * t + 8) * (OPX / 2)] = (u16)p23; Ow[(16 * t + 12) * (OPX / 2)] = (u16)(p23 >> 16);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = f32x4{bv, bv, bv, bv};
+    };
+    auto store = [&](int yo, int ob) {
+        if (ABL & 2) return;
+        const unsigned vo = vst + (unsigned)yo * row_bytes + (yo >= ylo ? 0u : 0x80000000u);
+        const u32x4 o0 = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + (16 * wv + (lane >> 3)) * OPX + (lane & 7) * 16));
+        const u32x4 o1 = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + (16 * wv + 8 + (lane >> 3)) * OPX + (lane & 7) * 16));
+        if (!(ABL & 16)) {
+            __builtin_amdgcn_raw_buffer_store_b128(o0, ry, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o1, ry, vo, 8 * C * 2, 0);
+        } else { asm volatile("" :: "v"(o0), "v"(o1)); }
+    };
+
+    const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3);
+    const u16* rd = T + blk * P + 4 * q;
+#pragma unroll
+    for (int i = 0; i < RS; ++i) dma(min(r_lo + i, r_hi - 1), (r_lo + i) % RS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    transpose(r_lo % RS);
+    int r = r_lo, slot = r_lo % RS, ob = 0;        // slot: raw slot of row r
+    for (;;) {
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            if (!(ABL & 1)) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    s16x4 a[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) a[t] = *(const s16x4*)&rd[16 * t + 4 * s];
+#pragma unroll
+                    for (int ky = 6; ky >= 0; --ky)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[t]), "v"(bop[ky][s]));
+                }
+            }
+            asm volatile("s_nop 7" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
+            stage(acc[u], ob);
+            // own pieces of row r + 1 landed (loads only are counted: stores may retire ahead of older loads); LDS writes retired
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (RS - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nslot = slot + 1 == RS ? 0 : slot + 1;
+            transpose(nslot);                          // row r + 1 -> T (the reads of row r are already issued: LDS is in order)
+            store(r - 3, ob);
+            if (!(ABL & 8)) dma(min(r + RS, r_hi - 1), slot);       // row r's slot: every wave has transposed it before this barrier
+            slot = nslot;
+            ob ^= 1;
+            if (++r >= r_hi) goto done;
+        }
+    }
+done:
+    for (int yo = max(ylo, r_hi - 3); yo < yhi; ++yo) {              // rows whose last input row lies below the image
+        const int sl = (yo - r_lo + 3) % 7;
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7)
+            if (s7 == sl) stage(acc[s7], ob);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        store(yo, ob);
+        ob ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 static void cpu_dw7(const std::vector<u16>& x, const std::vector<float>& w, const std::vector<float>& bias, std::vector<float>& out,
                     int B, int H, int W, int C)
 {
@@ -550,7 +729,12 @@ static void run_dw7(int B, int H, int W, int RC, bool check, int reps)
     const int grid = (int)((waves + 3) / 4);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&]() {
-        if constexpr (VER == 3) {
+        if constexpr (VER == 4) {
+            constexpr int WBY = RS * 72 * 64 * 2 + 2 * 64 * 144 + 4 * 16 * P * 2;
+            static bool once = false;
+            if (!once) { CK(hipFuncSetAttribute((const void*)dw7_mfma_v4<C, RS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, WBY)); once = true; }
+            dw7_mfma_v4<C, RS, ABL><<<(int)(waves / 4), 256, WBY>>>(dx, dy, dw, db, B, H, W, RC, nstrip, nchunk);
+        } else if constexpr (VER == 3) {
             constexpr int WBY = RS * (16 * NT + 8) * 32 + 2 * 16 * P * 2 + 16 * NT * 32;
             static bool once = false;
             if (!once) { CK(hipFuncSetAttribute((const void*)dw7_mfma_v3<NT, C, RS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WBY)); once = true; }
@@ -597,11 +781,20 @@ static void run_dw7(int B, int H, int W, int RC, bool check, int reps)
 
 int main(int argc, char** argv)
 {
-    run_dw7<4, 32, 2>(2, 40, 64, 16, true, 0);
-    run_dw7<2, 32, 2>(1, 32, 32, 32, true, 0);
-    run_dw7<4, 32, 3>(2, 40, 64, 16, true, 0);
-    run_dw7<4, 32, 3>(1, 23, 128, 32, true, 0);
-    run_dw7<4, 32, 3, 3>(1, 70, 192, 64, true, 0);
-    run_dw7<4, 32, 3, 4, 32>(1, 70, 192, 64, true, 0);
+    run_dw7<4, 64, 4>(2, 40, 64, 16, true, 0);
+    run_dw7<4, 64, 4>(1, 23, 128, 32, true, 0);
+    run_dw7<4, 128, 4, 3>(1, 70, 192, 64, true, 0);
+    const int reps = 20;
+    run_dw7<4, 384, 4>(32, 64, 64, 32, false, reps);
+    run_dw7<4, 192, 4>(32, 128, 128, 32, false, reps);
+    run_dw7<4, 384, 4, 4, 64>(32, 64, 64, 32, false, reps);
+    run_dw7<4, 192, 4, 4, 64>(32, 128, 128, 32, false, reps);
+    run_dw7<4, 384, 4>(32, 64, 64, 22, false, reps);
+    run_dw7<4, 384, 4>(32, 64, 64, 16, false, reps);
+    run_dw7<4, 192, 4>(32, 128, 128, 43, false, reps);
+    run_dw7<4, 192, 4>(32, 128, 128, 64, false, reps);
+    run_dw7<4, 192, 4, 4, 1>(32, 128, 128, 32, false, reps);
+    run_dw7<4, 192, 4, 4, 2>(32, 128, 128, 32, false, reps);
+    run_dw7<4, 192, 4, 4, 5>(32, 128, 128, 32, false, reps);
     return 0;
 }
