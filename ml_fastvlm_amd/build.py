@@ -27,7 +27,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # -pragma-unroll-threshold: the 48-slot software pipeline of ffn_fused.hip must be FULLY unrolled (all register-array
 # indices compile-time); above the default 16 K-instruction threshold LLVM silently keeps a loop and the accumulators
 # land in scratch (2.7 KB/lane).
-EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"]}
+EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"],
+               # dwconv_mfma.hip: 7 x 84 hand-placed MFMA slots, every register-array index compile-time (768 B/lane of scratch otherwise)
+               "dwconv_mfma.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 def _hipcc() -> str:

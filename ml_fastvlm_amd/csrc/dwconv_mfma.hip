@@ -39,22 +39,30 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int DWM_P = 80;        // pitch (px) of one channel row of the transposed image: (P/2) % 64 == 40 -> the 16 channels of an A read fall on 8 bank groups (2-way = the 512-B minimum)
-constexpr int DWM_OPX = 144;     // output staging: 128 B of channels + 16 B pad per pixel (the 4 pixels of one ds_write_b16 on 4 bank groups)
 constexpr int DWM_RS = 4;        // raw-row ring depth
-constexpr int DWM_RAWB = 72 * 128, DWM_OB = 64 * DWM_OPX, DWM_TB = 16 * DWM_P * 2;
-constexpr int DWM_LDS = DWM_RS * DWM_RAWB + 2 * DWM_OB + 4 * DWM_TB;
+// NW waves per workgroup = NW adjacent channel groups = 16 NW channels: 4 (64 channels = one 128-B line per pixel; C = 192, 384, ...)
+// or 6 (96 channels: with C = 96 the whole row segment of the strip is contiguous in memory)
+template <int NW> struct DwmCfg {
+    static constexpr int CW = 16 * NW, PXB = CW * 2;          // channels / bytes per pixel of the workgroup's block
+    static constexpr int OPX = PXB + 16;                      // output staging: one pixel + 16 B pad (the 4 pixels of one ds_write_b16 on 4 bank groups)
+    static constexpr int HALO = 64 * PXB;                     // byte offset of the halo pixels inside a raw row
+    static constexpr int RAWB = 72 * PXB, OB = 64 * OPX, TB = 16 * DWM_P * 2;       // TB: one transposed image; two per wave
+    static constexpr int LDS = DWM_RS * RAWB + 2 * OB + NW * 2 * TB;
+};
 
 FVHD_DEV u16 f32_to_bf16_rne(float f) { unsigned u = __float_as_uint(f); u += 0x7fff + ((u >> 16) & 1); return (u16)(u >> 16); }
 
-__global__ __launch_bounds__(256, 2) void dw7_mfma_kernel(const u16* __restrict__ x, u16* __restrict__ y, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, int H, int W, int C, int RC, int nstrip, int nchunk)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restrict__ x, u16* __restrict__ y, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int H, int W, int C, int RC, int nstrip, int nchunk)
 {
-    constexpr int NT = 4, CW = 64, SW = 64, IWX = 72, RS = DWM_RS, P = DWM_P, OPX = DWM_OPX, RAWB = DWM_RAWB, OB = DWM_OB, TBY = DWM_TB;
+    using K = DwmCfg<NW>;
+    constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = DWM_RS, P = DWM_P, OPX = K::OPX, RAWB = K::RAWB, OB = K::OB, TBY = K::TB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* raw = smem;                                       // [RS][8 interior pieces of 1 KiB | halo piece]
+    char* raw = smem;                                       // [RS][64 interior px | 8 halo px][PXB]  (NW = 4: chunks permuted inside every 1-KiB piece)
     char* O = smem + RS * RAWB;                             // [2][64 px][OPX]
-    u16* T = (u16*)(smem + RS * RAWB + 2 * OB + wv * TBY);  // per wave: [16 ch][P px], column 0..3 left halo, 4..67 strip, 68..71 right halo
+    u16* T = (u16*)(smem + RS * RAWB + 2 * OB + wv * 2 * TBY);  // per wave: [2][16 ch][P px], column 0..3 left halo, 4..67 strip, 68..71 right halo
     const int blk = lane >> 2, q = lane & 3;
     const int NCB = C / CW;
     int L = blockIdx.x;
@@ -80,34 +88,42 @@ __global__ __launch_bounds__(256, 2) void dw7_mfma_kernel(const u16* __restrict_
                 bop[ky][s][k] = (short)f32_to_bf16_rne(v);
             }
     const float bv = bias ? bias[c0 + blk] : 0.f;
+    f32x4 biasq = {bv, bv, bv, bv};
+    asm volatile("" : "+v"(biasq));            // one fixed register quad for the whole kernel (not re-materialised next to its readers)
     f32x4 acc[7][NT];
 #pragma unroll
     for (int sl = 0; sl < 7; ++sl)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[sl][t] = f32x4{bv, bv, bv, bv};
+        for (int t = 0; t < NT; ++t) acc[sl][t] = biasq;
 
-    // ---- loads.  Interior pieces 2 wv, 2 wv + 1 (8 px x 128 B each); inside a piece the 16-B chunks are stored
-    // [consumer wave][px][half], so that a wave's later ds_read_b128 of its 32-B column is bank-conflict free: DMA lane
-    // l = (consumer l >> 4, px (l >> 1) & 7, half l & 1) - the global side is still 8 whole lines.  Halo piece: plain
-    // [4 left px | 4 right px][128 B], lanes 16 wv .. 16 wv + 15 of every wave.  Pixels outside the image read a clamped
-    // (valid) address and are never transposed.
-    const int ipx = x0 + 16 * wv + ((lane >> 1) & 7);
-    const unsigned vint0 = (unsigned)((min(ipx, W - 1) * C + cb * CW) * 2 + (lane >> 4) * 32 + (lane & 1) * 16);
-    const unsigned vint1 = (unsigned)((min(ipx + 8, W - 1) * C + cb * CW) * 2 + (lane >> 4) * 32 + (lane & 1) * 16);
-    const int hp = lane >> 3, hx = hp < 4 ? x0 - 4 + hp : x0 + 60 + hp;
-    const unsigned vhalo = (unsigned)((min(max(hx, 0), W - 1) * C + cb * CW) * 2 + (lane & 7) * 16);
-    const unsigned long long hmask = 0xffffull << (16 * wv);
+    // ---- loads.  Every wave issues 2 of the 2 NW interior 1-KiB pieces and 16 lanes (256 B) of the halo pixels.
+    // NW = 4: a piece is 8 px x 128 B; inside it the 16-B chunks are stored [consumer wave][px][half], so that a wave's later
+    // ds_read_b128 of its 32-B column is bank-conflict free: DMA lane l = (consumer l >> 4, px (l >> 1) & 7, half l & 1) - the
+    // global side is still 8 whole lines.  NW = 6: plain byte order (a piece is 1 KiB of the contiguous 192-B pixels; the column
+    // read is 8-way conflicted, 12 instead of 6 cycles).  Halo: plain [4 left px | 4 right px][PXB].  Pixels outside the image read
+    // a clamped (valid) address and are never transposed.
+    auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + off); };
+    unsigned vint0, vint1;
+    if constexpr (NW == 4) {
+        const int ipx = x0 + 16 * wv + ((lane >> 1) & 7), off = (lane >> 4) * 32 + (lane & 1) * 16;
+        vint0 = goff(ipx, off); vint1 = goff(ipx + 8, off);
+    } else {
+        const int b0 = 2048 * wv + 16 * lane, b1 = b0 + 1024;
+        vint0 = goff(x0 + b0 / PXB, b0 % PXB); vint1 = goff(x0 + b1 / PXB, b1 % PXB);
+    }
+    const int hb = 256 * wv + 16 * (lane & 15), hp = hb / PXB;
+    const unsigned vhalo = goff(hp < 4 ? x0 - 4 + hp : x0 + 60 + hp, hb % PXB);
     const unsigned raw_lds = lds_addr(raw);
     auto dma = [&](int r, int slot) {
         const char* rb = ximg + (size_t)r * row_bytes;
-        const unsigned d0 = raw_lds + slot * RAWB + 2048 * wv, dh = raw_lds + slot * RAWB + 8192;
+        const unsigned d0 = raw_lds + slot * RAWB + 2048 * wv, dh = raw_lds + slot * RAWB + K::HALO + 256 * wv;
         unsigned keep; unsigned long long ex;
-        // M0 = LDS destination of the piece (+ lane * 16 by the hardware); s_add_u32 clobbers SCC
+        // M0 = LDS destination of the piece (+ lane * 16 by the hardware); the halo piece runs on lanes 0..15; s_add_u32 clobbers SCC
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
                      "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
-                     "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %8\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
+                     "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
                      "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&s"(ex) : "v"(vint0), "v"(vint1), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb), "s"(hmask) : "memory", "scc");
+                     : "=&s"(keep), "=&s"(ex) : "v"(vint0), "v"(vint1), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb) : "memory", "scc");
     };
     // ---- transposition source offsets / validity of this lane's three 16-B chunks (T column 32 m + lane / 2, channel half lane & 1)
     unsigned roff[3];
@@ -117,97 +133,157 @@ __global__ __launch_bounds__(256, 2) void dw7_mfma_kernel(const u16* __restrict_
         const int col = 32 * m + (lane >> 1), xi = x0 - 4 + col;
         okm[m] = col < IWX && xi >= 0 && xi < W;
         const int cc = min(col, IWX - 1), ip = cc - 4;
-        roff[m] = (unsigned)(cc < 4 ? 8192 + cc * 128 + wv * 32 + (lane & 1) * 16 : cc >= 68 ? 8192 + (cc - 64) * 128 + wv * 32 + (lane & 1) * 16
-                                    : (ip >> 3) * 1024 + wv * 256 + (ip & 7) * 32 + (lane & 1) * 16);
+        const int sub = wv * 32 + (lane & 1) * 16;
+        roff[m] = (unsigned)(cc < 4 ? K::HALO + cc * PXB + sub : cc >= 68 ? K::HALO + (cc - 64) * PXB + sub
+                                    : NW == 4 ? (ip >> 3) * 1024 + wv * 256 + (ip & 7) * 32 + (lane & 1) * 16 : ip * PXB + sub);
     }
-    auto transpose = [&](int slot) {           // raw[slot] -> T; the ds_reads of the previous row's A operands are already issued (LDS is in order)
+    // transposition in two halves so that the row loop can put MFMAs between the reads and the writes.  The writes are
+    // unconditional (no EXEC juggling inside the MFMA stream): lanes without a pixel of the image - halo columns outside it, lanes
+    // >= 16 of the third chunk - write into the 8 spare columns 72..79 of the pitch instead, and the columns outside the image keep
+    // their zeros.
+    unsigned tdst[3];                          // u16 index inside one T buffer
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            if (m == 2 && lane >= 16) continue;
-            const u32x4 v = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
-            if (okm[m]) {
-                u16* d = T + (8 * (lane & 1)) * P + 32 * m + (lane >> 1);
-                d[0 * P] = (u16)v.x; d[1 * P] = (u16)(v.x >> 16);
-                d[2 * P] = (u16)v.y; d[3 * P] = (u16)(v.y >> 16);
-                d[4 * P] = (u16)v.z; d[5 * P] = (u16)(v.z >> 16);
-                d[6 * P] = (u16)v.w; d[7 * P] = (u16)(v.w >> 16);
-            }
-        }
+    for (int m = 0; m < 3; ++m)
+        tdst[m] = (unsigned)((8 * (lane & 1)) * P + ((okm[m] && !(m == 2 && lane >= 16)) ? 32 * m + (lane >> 1) : IWX + ((lane >> 1) & 7)));
+    auto tr_read = [&](u32x4 (&v)[3], int slot) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) v[m] = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
+    };
+    auto tr_write1 = [&](const u32x4 (&v)[3], int tb, int m, int e) {       // element e (channel 8 half + e) of chunk m
+        u16* d = T + tb * (16 * P) + tdst[m];
+        const unsigned wv_ = e < 2 ? v[m].x : e < 4 ? v[m].y : e < 6 ? v[m].z : v[m].w;
+        d[e * P] = (e & 1) ? (u16)(wv_ >> 16) : (u16)wv_;
     };
     {
         f32x4 z = {0, 0, 0, 0};
-        for (int i = lane; i < TBY / 16; i += 64) *(f32x4*)((char*)T + i * 16) = z;
+        for (int i = lane; i < 2 * TBY / 16; i += 64) *(f32x4*)((char*)T + i * 16) = z;
     }
-    // ---- output: own 16 channels into the shared row buffer; then this wave stores pixels 16 wv .. 16 wv + 15 as whole lines.
-    // Pixels right of the image and rows above the chunk get an out-of-range buffer offset (dropped by the range check): no branches.
-    const int spx = x0 + 16 * wv + (lane >> 3);
-    const unsigned vst0 = (unsigned)((min(spx, W - 1) * C + cb * CW) * 2 + (lane & 7) * 16), oob0 = spx < W ? 0u : 0x80000000u;
-    const unsigned vst1 = (unsigned)((min(spx + 8, W - 1) * C + cb * CW) * 2 + (lane & 7) * 16), oob1 = spx + 8 < W ? 0u : 0x80000000u;
-    auto stage = [&](f32x4 (&a)[NT], int ob) {
-        u16* Ow = (u16*)(O + ob * OB + q * OPX + wv * 32 + blk * 2);
+    // ---- output: own 16 channels into the shared row buffer; then this wave stores 2 of the 2 NW 1-KiB pieces of the row (whole
+    // lines).  Pixels right of the image and rows above the chunk get an out-of-range buffer offset (dropped by the range check).
+    const int sb0 = 2048 * wv + 16 * lane, sb1 = sb0 + 1024;                 // byte inside the [64 px][PXB] output row
+    const int spx0 = x0 + sb0 / PXB, spx1 = x0 + sb1 / PXB;
+    const unsigned vst0 = goff(spx0, sb0 % PXB), oob0 = spx0 < W ? 0u : 0x80000000u;
+    const unsigned vst1 = goff(spx1, sb1 % PXB), oob1 = spx1 < W ? 0u : 0x80000000u;
+    const unsigned ord0 = (unsigned)((sb0 / PXB) * OPX + sb0 % PXB), ord1 = (unsigned)((sb1 / PXB) * OPX + sb1 % PXB);
+    auto stage_cvt = [&](unsigned (&pk)[2 * NT], f32x4 (&a)[NT]) {      // 8 packed pairs (px 16 t + {0, 4}, px 16 t + {8, 12})
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const unsigned p01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a[t][0], a[t][1]}, bf16x2_t));
-            const unsigned p23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a[t][2], a[t][3]}, bf16x2_t));
-            Ow[(16 * t + 0) * (OPX / 2)] = (u16)p01; Ow[(16 * t + 4) * (OPX / 2)] = (u16)(p01 >> 16);
-            Ow[(16 * t + 8) * (OPX / 2)] = (u16)p23; Ow[(16 * t + 12) * (OPX / 2)] = (u16)(p23 >> 16);
-            a[t] = f32x4{bv, bv, bv, bv};
+            pk[2 * t] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a[t][0], a[t][1]}, bf16x2_t));
+            pk[2 * t + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a[t][2], a[t][3]}, bf16x2_t));
         }
     };
-    auto store = [&](int yo, int ob) {
-        const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;     // valid offsets are < 2^31: the flags are OR-ed in
+    auto stage_write1 = [&](const unsigned (&pk)[2 * NT], int ob, int j) {  // j = 0..15: pixel 16 (j / 4) + 4 (j % 4) + q
+        u16* Ow = (u16*)(O + ob * OB + q * OPX + wv * 32 + blk * 2);
+        const unsigned v = pk[j >> 1];
+        Ow[(16 * (j >> 2) + 4 * (j & 3)) * (OPX / 2)] = (j & 1) ? (u16)(v >> 16) : (u16)v;
+    };
+    auto stage = [&](f32x4 (&a)[NT], int ob) {
+        unsigned pk[2 * NT];
+        stage_cvt(pk, a);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) stage_write1(pk, ob, j);
+    };
+    auto o_read = [&](u32x4 (&o)[2], int ob) {
         // same element type as the ds_write_b16 side (strict aliasing: a u32x4 load was hoisted above the u16 stores)
-        const u32x4 o0 = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + (16 * wv + (lane >> 3)) * OPX + (lane & 7) * 16));
-        const u32x4 o1 = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + (16 * wv + 8 + (lane >> 3)) * OPX + (lane & 7) * 16));
-        __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (vst0 + ro) | oob0 | oobr, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (vst1 + ro) | oob1 | oobr, 0, 0);
+        o[0] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + ord0));
+        o[1] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + ord1));
+    };
+    auto o_store = [&](const u32x4 (&o)[2], int yo) {
+        const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;     // valid offsets are < 2^31: the flags are OR-ed in
+        __builtin_amdgcn_raw_buffer_store_b128(o[0], ry, (vst0 + ro) | oob0 | oobr, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o[1], ry, (vst1 + ro) | oob1 | oobr, 0, 0);
     };
 
     // ---- rows.  Input rows [r_lo, r_hi); the slot of output row yo is (yo - r_lo + 3) % 7, so the unrolled sequence starts at u = 0.
+    // One iteration = one input row r (already transposed in T[tb]):
+    //     barrier: raw row r + 1 and the staged output row r - 4 are complete for every wave
+    //     LDS reads issued up front (A operands of segment 0, this wave's column of raw row r + 1, its pieces of output row r - 4)
+    //     28 MFMAs | stores + next DMA, 16 transposing writes | 28 MFMAs | 8 transposing writes | 28 MFMAs | stage output row r - 3
+    // so that a wave's LDS traffic and its MFMAs overlap inside the wave (with one workgroup per CU - the 96-channel case - nothing
+    // else would), and the per-row memory instructions sit behind the first MFMA group instead of in front of a stall.
     const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3);
     const u16* rd = T + blk * P + 4 * q;
 #pragma unroll
     for (int i = 0; i < RS; ++i) dma(min(r_lo + i, r_hi - 1), (r_lo + i) % RS);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    transpose(r_lo % RS);
-    int r = r_lo, slot = r_lo % RS, ob = 0;                 // slot: raw slot of row r
+    {
+        u32x4 v[3];
+        tr_read(v, r_lo % RS);
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tr_write1(v, 0, m, e);
+    }
+    int r = r_lo, slot = r_lo % RS, ob = 0, tb = 0;         // slot: raw slot of row r; ob: staging buffer of output row r - 3; tb: T buffer of row r
     for (;;) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
-            // every input row feeds the 7 output rows r - 3 .. r + 3, no branches: rows outside [ylo, yhi) are never stored and
-            // their slot is re-initialised before its next owner's first contribution.  Order (s, ky, tile): 27 independent
-            // MFMAs between two updates of one accumulator; ky = 6 first, so the slot staged after this row gets its last
-            // update earliest.  "+v" ties the accumulator in place (the builtin let the allocator copy all 112 around).
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                s16x4 a[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) a[t] = *(const s16x4*)&rd[16 * t + 4 * s];
-#pragma unroll
-                for (int ky = 6; ky >= 0; --ky)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[t]), "v"(bop[ky][s]));
-            }
-            // pin the readers of this slot behind the MFMAs and their XDL-write -> VALU-read wait states: unpinned, the first
-            // v_cvt of tile 3 was scheduled right behind its last MFMA and read stale registers
-            asm volatile("s_nop 7" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
-            stage(acc[u], ob);
             // own pieces of row r + 1 have landed once at most the RS - 2 later rows' pieces are outstanding (only loads are
-            // counted: stores may retire ahead of older loads); own LDS writes retired; then every wave's are
+            // counted: stores may retire ahead of older loads); own staging writes of the previous iteration retired
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (RS - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
             const int nslot = slot + 1 == RS ? 0 : slot + 1;
-            transpose(nslot);
-            store(r - 3, ob);
-            dma(min(r + RS, r_hi - 1), slot);               // row r's slot: every wave transposed it before this barrier
+            s16x4 a[3][NT];                                     // A operands of the three segments
+            u32x4 tv[3], ov[2];
+            unsigned pk[2 * NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[0][t] = *(const s16x4*)&rd[tb * (16 * P) + 16 * t];
+            tr_read(tv, nslot);
+            o_read(ov, ob ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // 84 MFMAs in the order (segment s, tap row ky = 6..0, tile t): 27 independent MFMAs between two updates of one
+            // accumulator; ky = 6 first, so the slot staged at the end gets its last update earliest.  "+v" ties the accumulator in
+            // place (the builtin let the allocator copy all 112 around).  Every input row feeds the 7 output rows r - 3 .. r + 3
+            // without branches: rows outside [ylo, yhi) are never stored, their slot is re-initialised before its next owner's
+            // first contribution.  The row's other instructions are dealt out ONE PER MFMA behind fixed positions of the stream
+            // (an 8-cycle MFMA leaves one issue slot): they overlap the matrix pipe inside the wave instead of stalling in bursts.
+#pragma unroll
+            for (int k = 0; k < 84; ++k) {
+                const int s = k / 28, ky = 6 - (k % 28) / 4, t = k % 4;
+                // a slot starts its life (output row r + 3: ky = 0 of segment 0) with C = the bias quad instead of being re-initialised
+                // by VALU moves: the register allocator placed those moves directly in front of the MFMA that reads them, and an
+                // inline-asm MFMA gets no VALU-write -> MFMA-read wait states from the compiler (wrong sums in 2 of 4 registers)
+                if (s == 0 && ky == 0)
+                    asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[s][t]), "v"(bop[ky][s]), "v"(biasq));
+                else
+                    asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[s][t]), "v"(bop[ky][s]));
+                if (k == 2) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) a[1][tt] = *(const s16x4*)&rd[tb * (16 * P) + 16 * tt + 4];
+                }
+                if (k == 5) o_store(ov, r - 4);                 // staged in the previous iteration
+                if (k == 8) dma(min(r + RS, r_hi - 1), slot);   // row r's slot: every wave transposed it before this iteration's barrier
+                if (k >= 10 && k < 18) tr_write1(tv, tb ^ 1, 0, k - 10);
+                if (k >= 18 && k < 26) tr_write1(tv, tb ^ 1, 1, k - 18);
+                if (k == 30) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) a[2][tt] = *(const s16x4*)&rd[tb * (16 * P) + 16 * tt + 8];
+                }
+                if (k >= 32 && k < 40) tr_write1(tv, tb ^ 1, 2, k - 32);
+                if (k == 62) {
+                    // the slot's last update was MFMA 56..59: pin its readers behind the stream position (the compiler does not
+                    // know the asm statements are MFMAs and once scheduled the first v_cvt right behind the last MFMA: stale registers)
+                    asm volatile("" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
+                    stage_cvt(pk, acc[u]);
+                }
+                if (k >= 64 && k < 80) stage_write1(pk, ob, k - 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             slot = nslot;
             ob ^= 1;
+            tb ^= 1;
             if (++r >= r_hi) goto done;
         }
     }
 done:
+    {   // the row staged by the last iteration
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        u32x4 ov[2];
+        o_read(ov, ob ^ 1);
+        o_store(ov, r_hi - 4);
+    }
     for (int yo = max(ylo, r_hi - 3); yo < yhi; ++yo) {     // rows whose last input row lies below the image
         const int sl = (yo - r_lo + 3) % 7;
 #pragma unroll
@@ -215,7 +291,9 @@ done:
             if (s7 == sl) stage(acc[s7], ob);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        store(yo, ob);
+        u32x4 ov[2];
+        o_read(ov, ob);
+        o_store(ov, yo);
         ob ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the LDS is released
@@ -223,28 +301,34 @@ done:
 
 }  // namespace
 
+template <int NW>
+static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)
+{
+    static bool attr_set[64] = {};                           // per device (one process may drive several contexts)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)dw7_mfma_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, DwmCfg<NW>::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev & 63] = true;
+    }
+    const int RC = 32;                                       // rows per chunk: 38 input rows per 32 output rows; measured best of 16 / 22 / 32 / 43 / 64
+    const int nstrip = (W + 63) / 64, nchunk = (H + RC - 1) / RC;
+    const long long grid = (long long)B * (C / (16 * NW)) * nstrip * nchunk;
+    if (grid <= 0 || grid > 0x7fffffffll) return (int)hipErrorInvalidValue;
+    dw7_mfma_kernel<NW><<<(int)grid, 64 * NW, DwmCfg<NW>::LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk);
+    return (int)hipGetLastError();
+}
+
 // 1 = this kernel takes the shape (the caller falls back to the VALU kernel otherwise)
 extern "C" int fvhd_dw7_mfma_supported(int H, int W, int C)
 {
-    return C % 64 == 0 && W >= 64 && H >= 1 && (long long)H * W * C * 2 < (1ll << 31);
+    return (C % 64 == 0 || C % 96 == 0) && W >= 64 && H >= 1 && (long long)H * W * C * 2 < (1ll << 31);
 }
 
 // x, y [B, H, W, C] bf16 (NHWC); w fp32 [49][C]; bias fp32 [C] or null
 extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)
 {
     if (!fvhd_dw7_mfma_supported(H, W, C)) return (int)hipErrorInvalidValue;
-    static bool attr_set[64] = {};                           // per device (one process may drive several contexts)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)dw7_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DWM_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set[dev & 63] = true;
-    }
-    const int RC = 32;                                       // rows per chunk: 38 input rows per 32 output rows; measured best of 16 / 22 / 32 / 43 / 64
-    const int nstrip = (W + 63) / 64, nchunk = (H + RC - 1) / RC;
-    const long long grid = (long long)B * (C / 64) * nstrip * nchunk;
-    if (grid <= 0 || grid > 0x7fffffffll) return (int)hipErrorInvalidValue;
-    dw7_mfma_kernel<<<(int)grid, 256, DWM_LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk);
-    return (int)hipGetLastError();
+    return C % 64 == 0 ? launch_dwm<4>(st, x, y, w, bias, B, H, W, C) : launch_dwm<6>(st, x, y, w, bias, B, H, W, C);
 }

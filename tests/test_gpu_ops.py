@@ -240,6 +240,9 @@ def _pack_dw(w):   # [Cout,1,K,K] -> fp32 [K*K][Cout]
     (7, 1, 1, 0, 64, 3, 64),       # fewer rows than taps
     (7, 1, 1, 0, 384, 64, 64),     # stage 3 of the 1024^2 tower
     (7, 1, 1, 0, 64, 33, 67),      # second strip 3 px wide
+    (7, 1, 1, 0, 96, 40, 128),     # 96-channel workgroups (6 waves): stage 1
+    (7, 1, 1, 0, 96, 37, 70),      # ... ragged strip and chunk
+    (7, 1, 1, 0, 192, 5, 256),     # 96 would also divide 192: the 64-channel path is taken
 ])
 def test_dwconv(K, S, mult, gelu, Cin, H, W):
     lib = _lib.load()

@@ -146,24 +146,26 @@ def bench_dw3cfg():
 
 
 def bench_dw7cfg():
+    """dw7x7 stride 1: 0 = VALU kernel (dwconv.hip), 1 = default dispatch (matrix-core kernel dwconv_mfma.hip where it applies)"""
     raw = C.CDLL(_lib.LIB_PATH)
-    for cfg in (1, 2, 3, 4):
+    for cfg in (0, 1):
         raw.fvhd_debug_set_dw7_cfg(cfg)
-        print(f"--- dw7 config {cfg}")
+        print(f"--- dw7 config {cfg} ({'VALU kernel' if cfg == 0 else 'default dispatch'})")
         _bench_dw(32, only_k7=True)
-    # every configuration must produce the same bits (same tap order, same fp32 accumulation), ragged sizes included
-    for Cc, H, B in ((96, 37, 3), (192, 20, 2), (384, 64, 2), (768, 32, 5), (1536, 16, 3), (96, 256, 2)):
+    # the two kernels round the taps differently (fp32 vs bf16 operands): agreement to bf16 resolution, ragged sizes included
+    for Cc, H, B in ((96, 70, 3), (192, 64, 2), (384, 64, 2), (768, 32, 5), (96, 256, 2)):
         x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
-        w = torch.randn(49, Cc, device=DEV)
+        w = torch.randn(49, Cc, device=DEV) / 7
         bias = torch.randn(Cc, device=DEV)
         outs = []
-        for cfg in (1, 2, 3, 4):
+        for cfg in (0, 1):
             raw.fvhd_debug_set_dw7_cfg(cfg)
             y = torch.full((B, H, H, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
             _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 7, 1, 1, 0))
             torch.cuda.synchronize()
-            outs.append(y.clone())
-        print(f"dw7 cfg agreement C={Cc} H={H} B={B}:", [bool(torch.equal(outs[0], o)) for o in outs[1:]])
+            outs.append(y.float())
+        d = (outs[0] - outs[1]).abs()
+        print(f"dw7 VALU vs MFMA C={Cc} H={H} B={B}: max |diff| {d.max().item():.4f}, rel-L2 {(d.norm() / outs[0].norm()).item():.2e}")
     raw.fvhd_debug_set_dw7_cfg(1)
 
 
