@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
-static int g_dw7_cfg = 1;    // debug: 0 = never the MFMA kernel (VALU kernel with the per-C choice), 1 = per-C choice, 3 = always 64-channel slices / 8-pixel strips, other = always 32 / 4
+static int g_dw7_cfg = 1;    // debug: 0 = never the MFMA kernel (VALU kernel with the per-C choice), 5 = the MFMA kernel also for small batches, 1 = per-C choice, 3 = always 64-channel slices / 8-pixel strips, other = always 32 / 4
 extern "C" void fvhd_debug_set_dw7_cfg(int m) { g_dw7_cfg = m; }
 static int g_dw3_cfg = 0;    // debug: 0 = register-prefetch tiles (64|32-channel slices, 8-pixel strips), 1/2 = LDS-DMA double buffer, 32/64-channel slices, 4-pixel strips
 extern "C" void fvhd_debug_set_dw3_cfg(int m) { g_dw3_cfg = m; }
@@ -406,7 +406,7 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
 }
 
 // x [B,H,W,Cin] bf16 -> y [B,OH,OW,Cin*mult] bf16; w fp32 [K*K][Cout]; bias fp32 [Cout] or null.
-extern "C" int fvhd_dw7_mfma_supported(int H, int W, int C);
+extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force);
 extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
 
 extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const float* w, const float* bias,
@@ -423,14 +423,14 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // dw7x7 stride 1 on the matrix cores (dwconv_mfma.hip) wherever the map is at least one 64-px strip wide and the channels
     // come in whole 128-B lines: 109 / 60 us at C = 192 / 384 (B = 32, 1024^2 input) against 246 / 118 for the VALU kernel
     // below, which stays for C = 96, narrow maps and as the comparison path (fvhd_debug_set_dw7_cfg(0)).
-    if (K == 7 && stride == 1 && mult == 1 && !gelu && g_dw7_cfg != 0 && fvhd_dw7_mfma_supported(H, W, Cin))
+    if (K == 7 && stride == 1 && mult == 1 && !gelu && g_dw7_cfg != 0 && fvhd_dw7_mfma_supported(B, H, W, Cin, g_dw7_cfg == 5))
         return fvhd_launch_dw7_mfma(st, x, y, w, bias, B, H, W, Cin);
     if (K == 7 && stride == 1 && mult == 1 && !gelu && c32) {
         // measured per channel count (tools/bench_ops.py dw7cfg, B = 32, us): config 4 = 32-channel slices / 4-pixel strips,
         // two LDS tile buffers filled by LDS-DMA during the tap loop, 2 waves per SIMD: 445 / 246 / 118 at C = 96 / 192 / 384
         // (2 = same tile, register staging, 3 waves per SIMD: 485 / 268 / 128).  From C = 768 on there are too few tiles
         // per workgroup for the prefetch to matter: config 2 at 768 (64), 64-channel slices / 8-pixel strips at >= 1536 (34).
-        const int vcfg = g_dw7_cfg == 0 ? 1 : g_dw7_cfg;
+        const int vcfg = (g_dw7_cfg == 0 || g_dw7_cfg == 5) ? 1 : g_dw7_cfg;
         const bool wide = c64 && (vcfg == 3 || (vcfg == 1 && Cin >= 1536));
         const bool dma = vcfg == 4 || (vcfg == 1 && Cin <= 384);
         if (dma) return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 2, 2>(st, xi, yo, w, bias, B, H, W, Cin);

@@ -301,6 +301,19 @@ done:
 
 }  // namespace
 
+// rows per chunk: 32 (38 input rows per 32 output rows - measured best of 16 / 22 / 32 / 43 / 64 at B = 32) while that still fills the
+// chip; smaller chunks for small batches (a workgroup is a serial march down its rows: 12 workgroups per image at stage 3 would
+// leave a B = 8 launch on 96 of 256 CUs); 0 = too few workgroups even at 8 rows -> the VALU kernel (finer tiles) is the better choice
+static int dwm_rows_per_chunk(int B, int H, int W, int C)
+{
+    const int nw = C % 64 == 0 ? 4 : 6;
+    const long long per_row_chunk = (long long)B * (C / (16 * nw)) * ((W + 63) / 64);
+    if (per_row_chunk * ((H + 31) / 32) >= 384) return 32;
+    if (per_row_chunk * ((H + 15) / 16) >= 256) return 16;
+    if (per_row_chunk * ((H + 7) / 8) >= 128) return 8;
+    return 0;
+}
+
 template <int NW>
 static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)
 {
@@ -312,7 +325,7 @@ static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, co
         if (e != hipSuccess) return (int)e;
         attr_set[dev & 63] = true;
     }
-    const int RC = 32;                                       // rows per chunk: 38 input rows per 32 output rows; measured best of 16 / 22 / 32 / 43 / 64
+    const int rc_ = dwm_rows_per_chunk(B, H, W, C), RC = rc_ > 0 ? rc_ : 8;
     const int nstrip = (W + 63) / 64, nchunk = (H + RC - 1) / RC;
     const long long grid = (long long)B * (C / (16 * NW)) * nstrip * nchunk;
     if (grid <= 0 || grid > 0x7fffffffll) return (int)hipErrorInvalidValue;
@@ -320,15 +333,16 @@ static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, co
     return (int)hipGetLastError();
 }
 
-// 1 = this kernel takes the shape (the caller falls back to the VALU kernel otherwise)
-extern "C" int fvhd_dw7_mfma_supported(int H, int W, int C)
+// 1 = this kernel takes the shape (the caller falls back to the VALU kernel otherwise); force: ignore the small-batch rule (tests)
+extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force)
 {
-    return (C % 64 == 0 || C % 96 == 0) && W >= 64 && H >= 1 && (long long)H * W * C * 2 < (1ll << 31);
+    if (!((C % 64 == 0 || C % 96 == 0) && W >= 64 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
+    return force || dwm_rows_per_chunk(B, H, W, C) > 0;
 }
 
 // x, y [B, H, W, C] bf16 (NHWC); w fp32 [49][C]; bias fp32 [C] or null
 extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)
 {
-    if (!fvhd_dw7_mfma_supported(H, W, C)) return (int)hipErrorInvalidValue;
+    if (!fvhd_dw7_mfma_supported(B, H, W, C, 1)) return (int)hipErrorInvalidValue;
     return C % 64 == 0 ? launch_dwm<4>(st, x, y, w, bias, B, H, W, C) : launch_dwm<6>(st, x, y, w, bias, B, H, W, C);
 }

@@ -37,6 +37,39 @@ FVHD_DEV int lds_off(int row, int ks)
     else return row * 64 + ((ks ^ ((0 - (row >> 2)) & 3)) << 4);
 }
 
+// ---- epilogue of one wave's (16 MF) x (16 NF) block: lane holds out[m][n .. n+3], m = mw + 16 i + lr, n = nw + 16 j + 4 g
+template <int MF, int NF, int EPI, int ODT>
+FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias, const float* __restrict__ ls, const bf16* resid, void* out,
+                            int M, int N, int mw, int nw, int lr, int g)
+{
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = nw + j * 16 + g * 4;
+        if (n >= N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, lv = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (EPI != EPI_NONE) bv = *(const f32x4*)(bias + n);
+        if constexpr (EPI == EPI_BIAS_LS_RESID) lv = *(const f32x4*)(ls + n);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = mw + i * 16 + lr;
+            if (m >= M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+            }
+            const size_t o = (size_t)m * N + n;
+            if constexpr (EPI == EPI_BIAS_LS_RESID) {
+                const f32x4 r = bf4_to_f32(*(const bf16x4*)(resid + o));
+                v = r + lv * v;
+            }
+            if constexpr (ODT == FVHD_BF16) *(bf16x4*)((bf16*)out + o) = f32_to_bf4(v);
+            else if constexpr (ODT == FVHD_F16) *(f16x4*)((_Float16*)out + o) = __builtin_convertvector(v, f16x4);
+            else *(f32x4*)((float*)out + o) = v;
+        }
+    }
+}
+
 template <int NF, int BK, int EPI, int ODT>
 __global__ __launch_bounds__(256) void gemm_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
@@ -129,33 +162,122 @@ __global__ __launch_bounds__(256) void gemm_kernel(
         }
     }
 
-    // ---- epilogue: lane holds out[m][n .. n+3], m = ..+lr, n = ..+4*g -------------------------------
+    gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 64, n0 + wn * 16 * NF, lr, g);
+}
+
+// ---- v2: 256 x 128 tile, 8 waves, K tiles of 64 streamed by LDS-DMA through a ring of 3 stages ---------------------------
+// v1 prefetches ONE K tile in registers: one MFMA block (~0.2 us) of cover against ~1-2 us of L2/HBM latency - rocprofv3 showed
+// the stage-3/4 GEMMs at 22-31 % MFMA-busy with the waves waiting on vmcnt.  Here two K tiles (96 KB per CU) are in flight
+// behind a counted vmcnt, no staging registers, ONE barrier per K tile (the barrier that publishes tile kt also retires tile
+// kt - 1, whose stage the next DMA overwrites).  The LDS image is the same XOR-swizzled one as v1's (conflict-free ds_read_b128
+// fragments): LDS-DMA writes lane-linearly, so the swizzle is applied on the GLOBAL side - lane l of a 1-KiB piece (8 rows x
+// 128 B) fetches the 16-B chunk ks = (l & 7) ^ ((row >> 1) & 7) of row (l >> 3): still 8 whole 128-B lines per instruction.
+// Each wave issues 4 of the 32 A pieces and 2 of the 16 W pieces of a K tile.  Taken when M % 256 == 0, N % 128 == 0, K % 64 == 0.
+constexpr int G2_RS = 3, G2_STAGE = (256 + 128) * 128;
+
+FVHD_DEV void glds_piece(unsigned voff, const void* sbase, unsigned m0v)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0v) : "memory");
+}
+
+template <int EPI, int ODT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ ls, const bf16* resid, void* out, int M, int N, int K, int tiles_n, int nwg)
+{
+    // NWV = 8: waves 4 (M) x 2 (N), 64 x 64 each (two per SIMD).  NWV = 4: 2 x 2, 128 x 64 each - 12 instead of 16 fragment reads per 32 MFMAs
+    // (the LDS pipe is the co-bottleneck: 8 ds_read_b128 per 16 MFMAs keep it ~75 % busy), one wave per SIMD.
+    constexpr int BM = 256, BN = 128, BK = 64, MF = 32 / NWV, NF = 4, RS = G2_RS, PA = 32 / NWV, PW = 16 / NWV;
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, g = lane >> 4;
+    const int L = xcd_remap(blockIdx.x, nwg);               // same super-tile order as v1 (8 x 8 tiles share their panels in one XCD's L2)
+    constexpr int GN = 8;
+    const int tiles_m = nwg / tiles_n;
+    const int grp = L / (tiles_m * GN), rem = L - grp * tiles_m * GN;
+    const int wg = min(GN, tiles_n - grp * GN);
+    const int tm = rem / wg, tn = grp * GN + (rem - tm * wg);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // per-lane global byte offsets of this wave's pieces: rows 8 p + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7); the swizzle
+    // term depends on the piece's parity only, the row base of a piece goes into the scalar base
+    const int rip = lane >> 3;
+    unsigned va[2], vw[2];
 #pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int n = n0 + wn * 16 * NF + j * 16 + g * 4;
-        if (n >= N) continue;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, lv = f32x4{1.f, 1.f, 1.f, 1.f};
-        if constexpr (EPI != EPI_NONE) bv = *(const f32x4*)(bias + n);
-        if constexpr (EPI == EPI_BIAS_LS_RESID) lv = *(const f32x4*)(ls + n);
+    for (int par = 0; par < 2; ++par) {
+        const int sw = ((par * 8 + rip) >> 1) & 7;
+        va[par] = (unsigned)((rip * K + (((lane & 7) ^ sw) * 8)) * 2);
+        vw[par] = va[par];
+    }
+    const char* abase = (const char*)(A + (size_t)(m0 + wave * 8 * PA) * K);   // A pieces PA wave .. PA wave + PA - 1 = rows 8 PA wave ..
+    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * 8 * PW) * K);  // W pieces PW wave ..
+    const unsigned lds0 = lds_addr(lds2);
+    auto issue = [&](int kt) {
+        const unsigned st = lds0 + (kt % RS) * G2_STAGE;
+        const size_t ko = (size_t)kt * BK * 2;
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + lr;
-            if (m >= M) continue;
-            f32x4 v = acc[i][j] + bv;
-            if constexpr (EPI == EPI_BIAS_GELU) {
+        for (int j = 0; j < PA; ++j) glds_piece(va[j & 1], abase + (size_t)j * 8 * K * 2 + ko, st + (wave * PA + j) * 1024);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
-            }
-            const size_t o = (size_t)m * N + n;
-            if constexpr (EPI == EPI_BIAS_LS_RESID) {
-                const f32x4 r = bf4_to_f32(*(const bf16x4*)(resid + o));
-                v = r + lv * v;
-            }
-            if constexpr (ODT == FVHD_BF16) *(bf16x4*)((bf16*)out + o) = f32_to_bf4(v);
-            else if constexpr (ODT == FVHD_F16) *(f16x4*)((_Float16*)out + o) = __builtin_convertvector(v, f16x4);
-            else *(f32x4*)((float*)out + o) = v;
+        for (int j = 0; j < PW; ++j) glds_piece(vw[j & 1], wbase + (size_t)j * 8 * K * 2 + ko, st + 256 * 128 + (wave * PW + j) * 1024);
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int i = 0; i < RS - 1; ++i)
+        if (i < nk) issue(i);
+    for (int kt = 0; kt < nk; ++kt) {
+        // own pieces of tile kt have landed when at most the one later tile's PA + PW are outstanding (loads only in this loop)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // tile kt visible to every wave; tile kt - 1 fully consumed
+        if (kt + RS - 1 < nk) issue(kt + RS - 1);     // into the stage tile kt - 1 occupied
+        const char* ldsA = lds2 + (kt % RS) * G2_STAGE;
+        const char* ldsW = ldsA + 256 * 128;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[MF], wf[NF];
+            const int ks = kk * 4 + g;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(ldsA + lds_off<BK>(wm * 16 * MF + i * 16 + lr, ks));
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const bf16x8*)(ldsW + lds_off<BK>(wn * 64 + j * 16 + lr, ks));
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
+    gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 16 * MF, n0 + wn * 64, lr, g);
+}
+
+static int g_gemm_v2 = 1;          // debug / A-B: 0 = always the v1 kernel
+extern "C" void fvhd_debug_set_gemm_v2(int on) { g_gemm_v2 = on; }
+
+template <int EPI, int ODT, int NWV>
+static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
+                                 const bf16* resid, void* out, int M, int N, int K)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_RS * G2_STAGE);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    const int tiles_m = M / 256, tiles_n = N / 128, nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV>), dim3(nwg), dim3(64 * NWV), G2_RS * G2_STAGE, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+    return hipGetLastError();
 }
 
 template <int NF, int BK, int EPI, int ODT>
@@ -197,6 +319,18 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     const bf16* a = (const bf16*)A;
     const bf16* w = (const bf16*)Wt;
     const bf16* r = (const bf16*)resid;
+    // streaming kernel where it has at least two full rounds of tiles (one 8-wave workgroup per CU): measured against v1 at B = 32
+    // (tools/bench_ops.py gemm, profiles/r02_gemm_v1_v2.log) fc1 272 -> 264 us, fc2 (K = 3072) 215 -> 196, stage-5 qkv 177 -> 155,
+    // projector fc 68 -> 56; with 384 tiles (stage-5 proj / fc2, 1.5 rounds) v1 stays ahead.  A 4-wave variant with 128 x 64 per
+    // wave (fewer fragment reads, one wave per SIMD) was 10-25 % slower: nothing covers the LDS read latency.
+    if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128 && (long long)(M / 256) * (N / 128) >= 512) {
+        switch (epi) {
+        case EPI_NONE: return (int)launch_gemm256<EPI_NONE, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
+        case EPI_BIAS: return (int)launch_gemm256<EPI_BIAS, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
+        case EPI_BIAS_GELU: return (int)launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
+        case EPI_BIAS_LS_RESID: return (int)launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
+        }
+    }
     const bool nf3 = (N % 128 != 0) && (N % 96 == 0);
     const bool bk64 = (K % 64 == 0);
     hipError_t e;

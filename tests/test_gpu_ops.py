@@ -67,6 +67,14 @@ def _gemm(A, W, bias, ls, resid, epi, out_dtype=torch.bfloat16, inplace=False):
     return out
 
 
+def test_gemm_identity_asymmetric_streaming_kernel():
+    # the 256 x 128 streaming kernel applies its LDS swizzle on the global side of the DMA: A = I must return W^T exactly
+    n = 128                                                        # K = N = 128, M = 65536 rows of stacked identities: 512 tiles
+    W = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125.0
+    out = _gemm(torch.eye(n).repeat(512, 1), W, None, None, None, _lib.EPI_NONE)
+    assert torch.equal(out.float().cpu(), W.t().repeat(512, 1))
+
+
 def test_gemm_identity_asymmetric():
     # A = I, asymmetric W: out must equal W^T exactly (catches swapped C/D row/col mappings)
     n = 128
@@ -83,6 +91,10 @@ def test_gemm_identity_asymmetric():
     (77, 768, 3072, _lib.EPI_BIAS_LS_RESID),    # stage-3 fc2, long K
     (64, 896, 3072, _lib.EPI_BIAS),             # projector
     (1, 96, 96, _lib.EPI_BIAS),                 # single row
+    (8192, 2048, 128, _lib.EPI_BIAS_GELU),      # streaming 256x128 kernel (LDS-DMA ring; taken from 512 tiles on): 2 K tiles = prologue only
+    (4096, 4096, 192, _lib.EPI_BIAS_LS_RESID),  # ... 3 K tiles, layer scale + residual
+    (8192, 2304, 768, _lib.EPI_NONE),           # ... qkv of stage 4 at B = 8
+    (16384, 512, 256, _lib.EPI_BIAS),           # ... narrow N
 ])
 def test_gemm_epilogues(M, N, K, epi):
     A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
@@ -235,18 +247,18 @@ def _pack_dw(w):   # [Cout,1,K,K] -> fp32 [K*K][Cout]
     (7, 2, 2, 1, 192, 40, 25),     # stride 2, odd width
     (3, 2, 1, 1, 96, 70, 66),      # stem[1]: 3 tiles in y
     (3, 1, 2, 0, 64, 20, 20),
-    (7, 1, 1, 0, 192, 40, 128),    # matrix-core dw7 (dwconv_mfma.hip): two strips, two row chunks (second ragged)
-    (7, 1, 1, 0, 128, 70, 96),     # ragged second strip (W = 64 + 32), three chunks
-    (7, 1, 1, 0, 64, 3, 64),       # fewer rows than taps
-    (7, 1, 1, 0, 384, 64, 64),     # stage 3 of the 1024^2 tower
-    (7, 1, 1, 0, 64, 33, 67),      # second strip 3 px wide
-    (7, 1, 1, 0, 96, 40, 128),     # 96-channel workgroups (6 waves): stage 1
-    (7, 1, 1, 0, 96, 37, 70),      # ... ragged strip and chunk
-    (7, 1, 1, 0, 192, 5, 256),     # 96 would also divide 192: the 64-channel path is taken
 ])
-def test_dwconv(K, S, mult, gelu, Cin, H, W):
+def test_dwconv(K, S, mult, gelu, Cin, H, W, B=2, force_mfma=False):
     lib = _lib.load()
-    B, Cout = 2, Cin * mult
+    Cout = Cin * mult
+    if force_mfma:
+        import ctypes
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        raw.fvhd_debug_set_dw7_cfg(5)          # the matrix-core kernel also below its small-batch threshold
+        try:
+            return test_dwconv(K, S, mult, gelu, Cin, H, W, B)
+        finally:
+            raw.fvhd_debug_set_dw7_cfg(1)
     x = _bf(_rand(B, Cin, H, W, seed=1))
     w = _rand(Cout, 1, K, K, seed=2, scale=1.0 / K)
     b = _rand(Cout, seed=3, scale=0.2)
@@ -260,6 +272,23 @@ def test_dwconv(K, S, mult, gelu, Cin, H, W):
     if gelu:
         want = O.gelu(want)
     _close(y.permute(0, 3, 1, 2), want, what=f"dwconv K{K} S{S} m{mult}")
+
+
+@pytest.mark.parametrize("Cin,H,W,B,force", [
+    (192, 40, 128, 2, True),     # two strips, row chunks of 8 (last ragged)
+    (128, 70, 96, 2, True),      # ragged second strip (W = 64 + 32)
+    (64, 3, 64, 1, True),        # fewer rows than taps
+    (384, 64, 64, 2, True),      # stage 3 of the 1024^2 tower
+    (64, 33, 67, 2, True),       # second strip 3 px wide
+    (96, 40, 128, 2, True),      # 96-channel workgroups (6 waves): stage 1
+    (96, 37, 70, 3, True),       # ... ragged strip and chunk
+    (192, 5, 256, 2, True),      # 96 would also divide 192: the 64-channel path is taken
+    (192, 64, 64, 24, False),    # large enough to take the kernel by itself, 16-row chunks
+    (64, 96, 128, 40, False),    # ... 32-row chunks
+])
+def test_dwconv_matrix_core_kernel(Cin, H, W, B, force):
+    """dw7x7 stride 1 on the 16-block MFMA (csrc/dwconv_mfma.hip) against the fp32 conv"""
+    test_dwconv(7, 1, 1, 0, Cin, H, W, B, force_mfma=force)
 
 
 def test_dwconv_unsupported_channel_count_is_an_error():

@@ -158,7 +158,7 @@ def bench_dw7cfg():
         w = torch.randn(49, Cc, device=DEV) / 7
         bias = torch.randn(Cc, device=DEV)
         outs = []
-        for cfg in (0, 1):
+        for cfg in (0, 5):
             raw.fvhd_debug_set_dw7_cfg(cfg)
             y = torch.full((B, H, H, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
             _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 7, 1, 1, 0))
@@ -198,13 +198,18 @@ def bench_gemm(B=32):
               ("s4 fc1", B * 256, 6144, 1536, 2), ("s4 fc2", B * 256, 1536, 6144, 3),
               ("proj0 H896", B * 256, 896, 3072, 2), ("proj2 H896", B * 256, 896, 896, 1),
               ("proj0 H3584", B * 256, 3584, 3072, 2), ("proj2 H3584", B * 256, 3584, 3584, 1)]
-    for name, M, N, K, epi in shapes:
+    raw = C.CDLL(_lib.LIB_PATH)
+    for v2 in (0, 1):
+      raw.fvhd_debug_set_gemm_v2(v2)
+      print(f"--- gemm: {('v1 only (128x128, register prefetch)', 'default dispatch (256x128 LDS-DMA ring where it pays)')[v2]}")
+      for name, M, N, K, epi in shapes:
         A = torch.randn(M, K).to(DEV, torch.bfloat16)
         W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
         bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
         out = torch.randn(M, N).to(DEV, torch.bfloat16)
         t = timeit(lambda: _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(out), p(out), M, N, K, epi, 2)))
         print(f"gemm {name:12s} M={M:8d} N={N:5d} K={K:5d} epi={epi}: {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+    raw.fvhd_debug_set_gemm_v2(1)
 
 
 def bench_attn(B=32):
