@@ -119,6 +119,14 @@ int fvhd_profile_enable(fvhd_ctx* ctx, int on);
  * the tower dtype (mobileclip_encoder.py:85).  Also settable with the environment variable FVHD_ATTN_FP8=1 at fvhd_create. */
 int fvhd_set_attention_fp8(fvhd_ctx* ctx, int on);
 
+/* Kernel selection.  Default (0): every launch takes the fastest kernel for its shape INCLUDING the batch - below ~0.75 workgroups
+ * per CU the depthwise 7x7 runs on the VALU kernel instead of the matrix-core one and ConvFFN as two tiled GEMMs instead of the
+ * fused kernel (B = 1 at 1024^2: 4.3 -> 3.5 ms).  Results are then bit-identical for a given batch size (any order, any
+ * neighbours) and equal across batch sizes only to bf16 rounding.  on != 0: the choice depends on the shape of ONE image only, so
+ * an image produces the same bits in whatever batch it travels (dynamic batching with reproducible outputs).  The reference
+ * makes no such promise either way (cuDNN / MIOpen pick algorithms by shape). */
+int fvhd_set_batch_invariant(fvhd_ctx* ctx, int on);
+
 /* hipGraph replay: on != 0 makes fvhd_encode / fvhd_encode_images capture the interior steps of the tower (everything between
  * the stem, which reads the caller's images, and the head, which writes the caller's buffer: ~170 launches on two streams)
  * into one hipGraph per (batch, options) on the second call with that batch size and replay it from then on - the launch-bound

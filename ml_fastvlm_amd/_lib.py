@@ -51,6 +51,7 @@ def _declare(lib) -> None:
         "fvhd_op_attention_fp8": (ci, [vp, vp, vp, ci, ci, ci]),
         "fvhd_set_attention_fp8": (ci, [vp, ci]),
         "fvhd_set_graph": (ci, [vp, ci]),
+        "fvhd_set_batch_invariant": (ci, [vp, ci]),
         "fvhd_op_stem_conv": (ci, [vp, vp, ci, vp, vp, vp, ci, ci]),
         "fvhd_op_stem_fused": (ci, [vp, vp, ci, vp, vp, vp, vp, vp, ci, ci]),
         "fvhd_op_se_head": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
@@ -182,6 +183,10 @@ class Context:
     def set_attention_fp8(self, on: bool) -> None:
         """e4m3 MFMA operands in the MHSA core (BASELINE.json configs[4]); default off = bf16 operands."""
         check(load().fvhd_set_attention_fp8(self._h, int(bool(on))), "fvhd_set_attention_fp8")
+
+    def set_batch_invariant(self, on: bool) -> None:
+        """kernel choice by image shape only: an image gives the same bits in any batch (default off = fastest kernel per batch size)."""
+        check(load().fvhd_set_batch_invariant(self._h, int(bool(on))), "fvhd_set_batch_invariant")
 
     def set_graph(self, on: bool) -> None:
         """replay the interior steps as one hipGraph per batch size (launch-bound small batches)."""

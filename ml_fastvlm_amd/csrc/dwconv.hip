@@ -409,8 +409,10 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
 extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force);
 extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
 
+// batch_invariant != 0: the kernel choice may depend on the SHAPE of one image only, never on B (bit-identical rows whatever the
+// batch they travel in); 0: the fastest kernel for this B (the VALU dw7x7 below the matrix-core kernel's fill threshold)
 extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const float* w, const float* bias,
-                                  int B, int H, int W, int Cin, int K, int stride, int mult, int gelu)
+                                  int B, int H, int W, int Cin, int K, int stride, int mult, int gelu, int batch_invariant)
 {
     const bf16* xi = (const bf16*)x;
     bf16* yo = (bf16*)y;
@@ -423,7 +425,7 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // dw7x7 stride 1 on the matrix cores (dwconv_mfma.hip) wherever the map is at least one 64-px strip wide and the channels
     // come in whole 128-B lines: 109 / 60 us at C = 192 / 384 (B = 32, 1024^2 input) against 246 / 118 for the VALU kernel
     // below, which stays for C = 96, narrow maps and as the comparison path (fvhd_debug_set_dw7_cfg(0)).
-    if (K == 7 && stride == 1 && mult == 1 && !gelu && g_dw7_cfg != 0 && fvhd_dw7_mfma_supported(B, H, W, Cin, g_dw7_cfg == 5))
+    if (K == 7 && stride == 1 && mult == 1 && !gelu && g_dw7_cfg != 0 && fvhd_dw7_mfma_supported(B, H, W, Cin, batch_invariant || g_dw7_cfg == 5))
         return fvhd_launch_dw7_mfma(st, x, y, w, bias, B, H, W, Cin);
     if (K == 7 && stride == 1 && mult == 1 && !gelu && c32) {
         // measured per channel count (tools/bench_ops.py dw7cfg, B = 32, us): config 4 = 32-channel slices / 4-pixel strips,

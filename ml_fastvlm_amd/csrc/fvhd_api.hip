@@ -15,7 +15,7 @@
 
 // ---- kernel launchers (dwconv.hip, gemm.hip, attention.hip, stem_head.hip) -------------------------
 extern "C" {
-int fvhd_launch_dwconv(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int, int, int, int);
+int fvhd_launch_dwconv(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
 int fvhd_launch_stem_fused(hipStream_t, const void*, int, void*, const float*, const float*, const float*, const float*, int, int);
@@ -144,6 +144,7 @@ struct fvhd_ctx {
     // through the whole tower, and the MFMA-heavy ConvFFN kernels of one half co-run on the CUs with the VALU-bound
     // depthwise kernels / HBM-bound prologues of the other.  aux joins back into the caller's stream before returning.
     int dual = 1;
+    int batch_invariant = 0;     // fvhd_set_batch_invariant: kernel choice by image shape only (bit-identical rows in any batch)
     int attn_fp8 = 0;            // fvhd_set_attention_fp8 / FVHD_ATTN_FP8=1: e4m3 MFMA operands in MHSA (BASELINE.json configs[4])
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -151,7 +152,7 @@ struct fvhd_ctx {
     // The stem (reads the caller's images) and the head (writes the caller's buffer) stay outside the graph, so a cached
     // graph only holds library-owned pointers (workspace, packed weights) and is valid for any caller buffers.
     struct GraphEntry {
-        int B, attn_fp8, dual, fused;
+        int B, attn_fp8, dual, fused;   // fused: bit 0 fused ConvFFN, bit 1 batch-invariant dispatch
         char* ws;
         hipGraphExec_t exec;       // nullptr until the second call with this key (the first runs eagerly), or when capture failed
         bool failed;
@@ -372,7 +373,7 @@ int run_dw(fvhd_ctx* c, hipStream_t st, int cls, const DwW& w, const void* x, vo
            int stride, int mult, int gelu)
 {
     Scope s(c, st, cls);
-    CHECK_LAUNCH(fvhd_launch_dwconv(st, x, y, c->wp<float>(w.w), c->wp<float>(w.b), B, H, W, Cin, w.K, stride, mult, gelu),
+    CHECK_LAUNCH(fvhd_launch_dwconv(st, x, y, c->wp<float>(w.w), c->wp<float>(w.b), B, H, W, Cin, w.K, stride, mult, gelu, c->batch_invariant),
                  "dwconv launch");
     return 0;
 }
@@ -387,13 +388,18 @@ int run_gemm(fvhd_ctx* c, hipStream_t st, int cls, const char* wbase, const Gemm
     return 0;
 }
 
+constexpr int kFusedFfnMinRows = 24576;
+
 // ConvFFN + layer scale + residual, in place on x (mci.py:1106-1109 / 1185-1188 second line)
 int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, int B, int H, int Wd, int C)
 {
     const int M = B * H * Wd;
     int e;
     if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0))) return e;
-    if (f.fused && c->use_fused_ffn) {
+    // The fused kernel gives one workgroup 128 rows and walks the whole hidden dimension serially (48 chunks at C = 384: ~60 us
+    // however few rows there are).  Below ~0.75 workgroups per CU the two tiled GEMMs (hundreds of tiles even at M = 4096) finish
+    // sooner: B = 1 at 1024^2 runs stages 2 / 3 (M = 16384 / 4096) this way, 4.27 -> 3.4 ms per image.
+    if (f.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows)) {
         Scope s(c, st, C_FFN);
         CHECK_LAUNCH(fvhd_launch_ffn_fused(st, w.A, c->wdev + f.w1img, c->wp<float>(f.fc1.b), c->wdev + f.w2img,
                                            c->wp<float>(f.fc2.b), c->wp<float>(f.ls), x, M, C),
@@ -553,10 +559,10 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
     if ((e = run_step(c, st, c->m.steps[0], w, X0, T0, B, images, img_dtype, nullptr, 0))) return e;
     fvhd_ctx::GraphEntry* g = nullptr;
     for (auto& q : c->graphs)
-        if (q.B == B && q.attn_fp8 == c->attn_fp8 && q.dual == c->dual && q.fused == (int)c->use_fused_ffn && q.ws == c->ws) g = &q;
+        if (q.B == B && q.attn_fp8 == c->attn_fp8 && q.dual == c->dual && q.fused == ((int)c->use_fused_ffn | (c->batch_invariant << 1)) && q.ws == c->ws) g = &q;
     if (!g) {                              // first call with this key: eager (one-time kernel attributes are set on this pass)
         if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
-        c->graphs.push_back({B, c->attn_fp8, c->dual, (int)c->use_fused_ffn, c->ws, nullptr, false, X0, T0, X1, T1});
+        c->graphs.push_back({B, c->attn_fp8, c->dual, (int)c->use_fused_ffn | (c->batch_invariant << 1), c->ws, nullptr, false, X0, T0, X1, T1});
     } else if (g->failed) {
         if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
     } else {
@@ -878,6 +884,13 @@ int fvhd_set_attention_fp8(fvhd_ctx* c, int on)
     return 0;
 }
 
+int fvhd_set_batch_invariant(fvhd_ctx* c, int on)
+{
+    if (!c) return fail("fvhd_set_batch_invariant: ctx is NULL");
+    c->batch_invariant = on != 0;
+    return 0;
+}
+
 int fvhd_profile_enable(fvhd_ctx* c, int on)
 {
     if (!c) return fail("fvhd_profile_enable: ctx is NULL");
@@ -927,7 +940,7 @@ int fvhd_profile_read(fvhd_ctx* c, int max_classes, const char** names, double* 
 int fvhd_op_dwconv(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int Cin,
                    int K, int stride, int mult, int gelu)
 {
-    int e = fvhd_launch_dwconv((hipStream_t)st, x, y, w, bias, B, H, W, Cin, K, stride, mult, gelu);
+    int e = fvhd_launch_dwconv((hipStream_t)st, x, y, w, bias, B, H, W, Cin, K, stride, mult, gelu, 0);
     return e ? hip_fail("fvhd_op_dwconv", (hipError_t)e) : 0;
 }
 

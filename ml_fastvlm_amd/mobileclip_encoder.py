@@ -110,6 +110,8 @@ class MobileCLIPVisionTower(nn.Module):
         # ... and hipGraph replay of the tower's interior launches (include/fvhd.h: fvhd_set_graph), for launch-bound batches
         graph = getattr(args, "mm_vision_hip_graph", None)
         self.hip_graph = None if graph is None else bool(graph)
+        inv = getattr(args, "mm_vision_batch_invariant", None)
+        self.batch_invariant = None if inv is None else bool(inv)
         # expected batch size (sizes the library's workspace up front; it grows geometrically when a larger batch arrives)
         self._batch_hint = max(1, int(getattr(args, "mm_vision_max_batch", 1) or 1))
         self._ctx: Optional[_lib.Context] = None
@@ -183,6 +185,8 @@ class MobileCLIPVisionTower(nn.Module):
             self._ctx.set_attention_fp8(self.attention_fp8)
         if self.hip_graph is not None:
             self._ctx.set_graph(self.hip_graph)
+        if self.batch_invariant is not None:
+            self._ctx.set_batch_invariant(self.batch_invariant)
         return self._ctx
 
     # The ctypes handle is process-local state, not model state: copies / pickles of a tower start without a context and
