@@ -101,18 +101,22 @@ def pmc_traffic(kernel_class: str):
     if not files:
         return None, None
     prof = json.load(open(files[-1]))
-    parts = {"ffn_fused": ["ffn_fused_c384", "ffn_fused_c192", "ffn_fused_c96"], "dw7": ["dw7_s1"], "dw3": ["dw3_s1"],
+    parts = {"ffn_fused": ["ffn_fused_c384", "ffn_fused_c192", "ffn_fused_c96"], "dw7": ["dw7_mfma_c64 (C = 192, 384)", "dw7_mfma_c96 (C = 96)", "dw7_s1"], "dw3": ["dw3_s1"],
              "attention": ["attention"], "dw_down": ["dw_down"]}.get(kernel_class)
     if not parts:
         return None, None
     tot, n = 0.0, 0
     for cls in parts:
         c = prof.get(cls)
-        if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        if not c:
+            continue                                 # a class this build does not launch (e.g. no VALU dw7x7 at this batch size)
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             return None, None
         d = c["FETCH_SIZE"]["dispatches"]
         tot += d * 1024.0 * (2.0 * c["FETCH_SIZE"]["per_dispatch"] + c["WRITE_SIZE"]["per_dispatch"])
         n += d
+    if n == 0:
+        return None, None
     return tot / n, os.path.relpath(files[-1], ROOT)
 
 

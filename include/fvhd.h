@@ -14,6 +14,10 @@
  * context owns packed weights and workspace.  A context is bound to one device and is not
  * thread-safe (one context per stream/thread; the reference's callers enter `forward` one at a
  * time, llava/serve/model_worker.py:168-187).
+ *
+ * The multi-GPU boundary (one tower per rank + one all-gather of visual tokens) has NO entry point here on purpose: the
+ * collective belongs to the host framework's process group (RCCL through torch.distributed, ml_fastvlm_amd/distributed.py);
+ * the library produces the tokens a rank contributes.
  */
 #ifndef FVHD_H
 #define FVHD_H
@@ -142,6 +146,12 @@ int fvhd_profile_read(fvhd_ctx* ctx, int max_classes, const char** names, double
  * (K,stride,mult,gelu) in {(3,1,1,0),(3,2,1,1),(7,1,1,0),(7,2,2,1),(3,1,2,0)}  - mci.py:808-811, 575-586, 921, 992-995, 442-451, 1401-1411 */
 int fvhd_op_dwconv(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias,
                    int B, int H, int W, int Cin, int K, int stride, int mult, int gelu);
+
+/* The 7x7 stride-1 depthwise conv (+ bias) on the matrix cores (csrc/dwconv_mfma.hip: 16-block 4x4x4 bf16 MFMA, taps rounded to
+ * bf16, fp32 accumulation) for ANY batch size - fvhd_op_dwconv / the tower take this kernel by themselves once the launch fills
+ * the chip (or always, under fvhd_set_batch_invariant).  Same arguments as fvhd_op_dwconv(K = 7, stride 1, mult 1, no GELU);
+ * needs C % 64 == 0 or C % 96 == 0 and W >= 64, anything else is an error. */
+int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
 /* out[M,N] = epi(A[M,K] . Wt[N,K]^T): A, Wt, resid bf16; bias, ls fp32 [N]; K % 32 == 0, N % 16 == 0. */
 int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, const float* ls,
                  const void* resid, void* out, int M, int N, int K, int epilogue, int out_dtype);

@@ -45,6 +45,7 @@ def _declare(lib) -> None:
         "fvhd_profile_reset": (ci, [vp]),
         "fvhd_profile_read": (ci, [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(ci)]),
         "fvhd_op_dwconv": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci]),
+        "fvhd_op_dw7_mfma": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci]),
         "fvhd_op_gemm": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
         "fvhd_op_layernorm": (ci, [vp, vp, vp, vp, vp, ci, ci, cf]),
         "fvhd_op_attention": (ci, [vp, vp, vp, ci, ci, ci]),

@@ -48,7 +48,8 @@ def _newer(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
     """ablate=True (or FVHD_FFN_ABLATE=1 on the command line): the experiment library `libfvhd_ablate.so` with the fused-FFN
-    ablation variants compiled in (tools/bench_ops.py picks it with FVHD_LIB); never what the package loads by default."""
+    ablation variants and the kernel-selection knobs (fvhd_debug_set_*, -DFVHD_DEBUG_KNOBS) compiled in; tools/bench_ops.py picks
+    it with FVHD_LIB for A/B runs.  Never what the package loads by default: the shipped library has no such switches."""
     build_dir = BUILD + ("_ablate" if ablate else "")
     lib = LIB.replace("libfvhd.so", "libfvhd_ablate.so") if ablate else LIB
     os.makedirs(build_dir, exist_ok=True)
@@ -63,7 +64,7 @@ def build_library(force: bool = False, verbose: bool = False, ablate: bool = Fal
         o = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            extra = EXTRA_FLAGS.get(src, []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
+            extra = EXTRA_FLAGS.get(src, []) + (["-DFVHD_DEBUG_KNOBS"] if ablate else []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
             jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -10,130 +10,12 @@
 // where M is the channel multiplier (groups = Cin, Cout = M*Cin: output channel oc reads input
 // channel oc / M, which is PyTorch's grouped-conv convention).
 //
-// HBM-bound op.  Layout choices for gfx950:
-//   * NHWC so that the channel axis is contiguous: one lane owns 8 output channels (16 B of bf16),
-//     8 or 12 consecutive lanes cover a 128 B / 192 B contiguous run of one pixel -> coalesced
-//     16-B-per-lane loads and stores.
-//   * a workgroup owns one channel slice (64 or 96 output channels) x a run of output strips; the
-//     slice's K*K*CS fp32 taps are staged in LDS once per workgroup (<= 18.4 KiB) and read back as
-//     32-B-per-lane ds_read_b128 pairs (8 distinct addresses per wave, the rest broadcast).
-//   * each lane walks a strip of OWT output pixels along x and re-uses every loaded input vector
-//     for up to min(K, OWT) outputs, cutting the K*K loads per output to K*(OWT*S+K-S)/OWT.
-//   * blockIdx.x is remapped so each XCD (private L2) gets a contiguous range of rows: the K-1
-//     halo rows a workgroup shares with its vertical neighbours are then L2 hits, not HBM re-reads.
+// HBM-bound by its bytes, VALU-bound in practice for 7x7 (49 fp32 FMAs + bf16 unpacks per output).  NHWC so that the channel
+// axis is contiguous: one lane owns 8 output channels (16 B of bf16).  Two kernels:
+//   * dwconv_tiled_kernel (below): LDS-staged input tiles, taps in LDS, strips of 4-8 output pixels per lane - every shape;
+//   * dw7_mfma_kernel (dwconv_mfma.hip): the 7x7 stride-1 case on the 16-block 4x4x4 MFMA, taken by fvhd_launch_dwconv
+//     wherever the map is at least one 64-px strip wide and the channels come in whole 128-B / 192-B pixels.
 #include "fvhd_common.h"
-
-template <int K, int S, int MULT, bool ACT, int OWT>
-__global__ __launch_bounds__(256) void dwconv_kernel(
-    const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w,
-    const float* __restrict__ bias, int B, int H, int W, int Cin, int OH, int OW, int CS, int nblk_x)
-{
-    constexpr int PAD = K / 2;
-    constexpr int NIN = (OWT - 1) * S + K;      // input columns touched by one strip
-    constexpr int CI = 8 / MULT;                // input channels per lane
-    extern __shared__ __attribute__((aligned(16))) float lds_w[];   // [K*K][CS]
-    const int Cout = Cin * MULT;
-    const int slice = blockIdx.y;
-
-    for (int i = threadIdx.x; i < K * K * CS / 4; i += 256) {
-        const int e = i * 4, tap = e / CS, c = e - tap * CS;
-        *(f32x4*)&lds_w[e] = *(const f32x4*)&w[(size_t)tap * Cout + slice * CS + c];
-    }
-    __syncthreads();
-
-    const int LPP = CS >> 3;                    // lanes per pixel
-    const int SPB = 256 / LPP;                  // strips per block
-    const int tl = threadIdx.x;
-    if (tl >= SPB * LPP) return;
-    const int cgl = tl % LPP, sl = tl / LPP;
-    const int SX = (OW + OWT - 1) / OWT;
-    const long s = (long)xcd_remap(blockIdx.x, nblk_x) * SPB + sl;
-    if (s >= (long)B * OH * SX) return;
-    const int sx = (int)(s % SX);
-    const int oy = (int)((s / SX) % OH);
-    const int b = (int)(s / ((long)SX * OH));
-    const int ox0 = sx * OWT;
-    const int oc0 = slice * CS + cgl * 8;
-    const int ic0 = oc0 / MULT;
-
-    float acc[OWT][8];
-#pragma unroll
-    for (int o = 0; o < OWT; ++o)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[o][c] = bias ? bias[oc0 + c] : 0.0f;
-
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * S + ky - PAD;
-        if (iy < 0 || iy >= H) continue;
-        float wr[K][8];
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const f32x4 w0 = *(const f32x4*)&lds_w[(ky * K + kx) * CS + cgl * 8];
-            const f32x4 w1 = *(const f32x4*)&lds_w[(ky * K + kx) * CS + cgl * 8 + 4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { wr[kx][c] = w0[c]; wr[kx][4 + c] = w1[c]; }
-        }
-        const bf16* row = x + ((size_t)(b * H + iy) * W) * Cin + ic0;
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-            const int ix = ox0 * S - PAD + j;
-            float v[CI];
-            if (ix >= 0 && ix < W) {
-                if constexpr (CI == 8) {
-                    const f32x8 t = bf8_to_f32(*(const bf16x8*)(row + (size_t)ix * Cin));
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] = t[c];
-                } else {
-                    const f32x4 t = bf4_to_f32(*(const bf16x4*)(row + (size_t)ix * Cin));
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = t[c];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CI; ++c) v[c] = 0.0f;
-            }
-#pragma unroll
-            for (int o = 0; o < OWT; ++o) {
-                const int kx = j - o * S;
-                if (kx >= 0 && kx < K) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[o][c] = __builtin_fmaf(wr[kx][c], v[c / MULT], acc[o][c]);
-                }
-            }
-        }
-    }
-
-#pragma unroll
-    for (int o = 0; o < OWT; ++o) {
-        const int ox = ox0 + o;
-        if (ox >= OW) break;
-        f32x8 r;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) r[c] = ACT ? gelu_erf(acc[o][c]) : acc[o][c];
-        *(bf16x8*)(y + ((size_t)(b * OH + oy) * OW + ox) * Cout + oc0) = f32_to_bf8(r);
-    }
-}
-
-template <int K, int S, int MULT, bool ACT>
-static hipError_t launch_dw(hipStream_t st, const bf16* x, bf16* y, const float* w, const float* bias,
-                            int B, int H, int W, int Cin)
-{
-    constexpr int OWT = 4;
-    const int Cout = Cin * MULT;
-    const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
-    const int CS = (Cout % 64 == 0) ? 64 : 96;
-    if (Cout % CS != 0) return hipErrorInvalidValue;
-    const int SPB = 256 / (CS / 8);
-    const int SX = (OW + OWT - 1) / OWT;
-    const long strips = (long)B * OH * SX;
-    const int gx = (int)((strips + SPB - 1) / SPB);
-    dim3 grid(gx, Cout / CS);
-    const size_t shmem = (size_t)K * K * CS * sizeof(float);
-    hipLaunchKernelGGL((dwconv_kernel<K, S, MULT, ACT, OWT>), grid, dim3(256), shmem, st,
-                       x, y, w, bias, B, H, W, Cin, OH, OW, CS, gx);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------------------------------
 // LDS-tiled depthwise conv - the hot variant (38 dw3x3 + 46 dw7x7 + 4 dw7x7/s2 + the stem's dw3x3/s2 per forward).
@@ -367,12 +249,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
-static int g_dw7_cfg = 1;    // debug: 0 = never the MFMA kernel (VALU kernel with the per-C choice), 5 = the MFMA kernel also for small batches, 1 = per-C choice, 3 = always 64-channel slices / 8-pixel strips, other = always 32 / 4
+// Experiment knobs: compile-time constants in the shipped library; setters exist only in the debug build
+// (`FVHD_FFN_ABLATE=1 python -m ml_fastvlm_amd.build` -> libfvhd_ablate.so, -DFVHD_DEBUG_KNOBS; tools/bench_ops.py uses it for A/B runs).
+//   dw7 cfg: 0 = never the matrix-core kernel (VALU kernel with the per-C choice), 5 = the matrix-core kernel also below its
+//            small-batch threshold, 1 = default dispatch, 3 = VALU: always 64-channel slices / 8-pixel strips, other = always 32 / 4
+//   dw3 cfg: 0 = register-prefetch tiles (64|32-channel slices, 8-pixel strips), 1/2 = LDS-DMA double buffer, 32/64-channel slices
+//   dw mode: 1 = stage + store only (no tap loop), 2 = no staging loads (tap loop on stale LDS)
+#ifdef FVHD_DEBUG_KNOBS
+static int g_dw7_cfg = 1, g_dw3_cfg = 0, g_dw_mode = 0;
 extern "C" void fvhd_debug_set_dw7_cfg(int m) { g_dw7_cfg = m; }
-static int g_dw3_cfg = 0;    // debug: 0 = register-prefetch tiles (64|32-channel slices, 8-pixel strips), 1/2 = LDS-DMA double buffer, 32/64-channel slices, 4-pixel strips
 extern "C" void fvhd_debug_set_dw3_cfg(int m) { g_dw3_cfg = m; }
-static int g_dw_mode = 0;    // debug (tools/bench_ops.py): 1 = stage + store only (no tap loop), 2 = no staging loads (tap loop on stale LDS)
 extern "C" void fvhd_debug_set_dw_mode(int m) { g_dw_mode = m; }
+#else
+static constexpr int g_dw7_cfg = 1, g_dw3_cfg = 0, g_dw_mode = 0;
+#endif
 
 template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, int PREF = 1>
 static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const float* w, const float* bias,
@@ -424,7 +314,7 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // but executes in ~2.3, so the pipe only saturates with >= 3 waves per SIMD (tools/ubench/valu_rate.hip)
     // dw7x7 stride 1 on the matrix cores (dwconv_mfma.hip) wherever the map is at least one 64-px strip wide and the channels
     // come in whole 128-B lines: 109 / 60 us at C = 192 / 384 (B = 32, 1024^2 input) against 246 / 118 for the VALU kernel
-    // below, which stays for C = 96, narrow maps and as the comparison path (fvhd_debug_set_dw7_cfg(0)).
+    // below, which stays for C = 96, narrow maps and as the comparison path (debug build: fvhd_debug_set_dw7_cfg(0)).
     if (K == 7 && stride == 1 && mult == 1 && !gelu && g_dw7_cfg != 0 && fvhd_dw7_mfma_supported(B, H, W, Cin, batch_invariant || g_dw7_cfg == 5))
         return fvhd_launch_dw7_mfma(st, x, y, w, bias, B, H, W, Cin);
     if (K == 7 && stride == 1 && mult == 1 && !gelu && c32) {
@@ -451,10 +341,5 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     }
     DW_TILED(3, 1, 1, false) DW_TILED(7, 2, 2, true) DW_TILED(3, 2, 1, true) DW_TILED(3, 1, 2, false)
 #undef DW_TILED
-    if (K == 3 && stride == 1 && mult == 1 && !gelu) e = launch_dw<3, 1, 1, false>(st, xi, yo, w, bias, B, H, W, Cin);
-    else if (K == 3 && stride == 2 && mult == 1 && gelu) e = launch_dw<3, 2, 1, true>(st, xi, yo, w, bias, B, H, W, Cin);
-    else if (K == 7 && stride == 1 && mult == 1 && !gelu) e = launch_dw<7, 1, 1, false>(st, xi, yo, w, bias, B, H, W, Cin);
-    else if (K == 7 && stride == 2 && mult == 2 && gelu) e = launch_dw<7, 2, 2, true>(st, xi, yo, w, bias, B, H, W, Cin);
-    else if (K == 3 && stride == 1 && mult == 2 && !gelu) e = launch_dw<3, 1, 2, false>(st, xi, yo, w, bias, B, H, W, Cin);
     return (int)e;
 }

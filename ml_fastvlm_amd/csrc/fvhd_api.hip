@@ -16,6 +16,8 @@
 // ---- kernel launchers (dwconv.hip, gemm.hip, attention.hip, stem_head.hip) -------------------------
 extern "C" {
 int fvhd_launch_dwconv(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int, int, int, int, int);
+int fvhd_launch_dw7_mfma(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int);
+int fvhd_dw7_mfma_supported(int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
 int fvhd_launch_stem_fused(hipStream_t, const void*, int, void*, const float*, const float*, const float*, const float*, int, int);
@@ -987,6 +989,16 @@ int fvhd_op_se_head(fvhd_stream_t st, const void* y, float* pooled, float* scale
 {
     int e = fvhd_launch_se_head((hipStream_t)st, y, pooled, scale, wr, br, we, be, out, out_dtype, B, T, C, RD);
     return e ? hip_fail("fvhd_op_se_head", (hipError_t)e) : 0;
+}
+
+int fvhd_op_dw7_mfma(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)
+{
+    if (!x || !y || !w) return fail("fvhd_op_dw7_mfma: NULL pointer");
+    if (!fvhd_dw7_mfma_supported(B, H, W, C, 1))
+        return fail("fvhd_op_dw7_mfma: needs C % 64 == 0 or C % 96 == 0, W >= 64 and an image below 2 GiB (got B=" + std::to_string(B) + " H=" +
+                    std::to_string(H) + " W=" + std::to_string(W) + " C=" + std::to_string(C) + ")");
+    int e = fvhd_launch_dw7_mfma((hipStream_t)st, x, y, w, bias, B, H, W, C);
+    return e ? hip_fail("fvhd_op_dw7_mfma", (hipError_t)e) : 0;
 }
 
 int fvhd_op_ffn_fused(fvhd_stream_t st, const void* A, const void* w1img, const float* b1, const void* w2img, const float* b2,

@@ -260,8 +260,12 @@ __global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
     gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 16 * MF, n0 + wn * 64, lr, g);
 }
 
-static int g_gemm_v2 = 1;          // debug / A-B: 0 = always the v1 kernel
+#ifdef FVHD_DEBUG_KNOBS                 // A/B runs (tools/bench_ops.py gemm on libfvhd_ablate.so): 0 = always the v1 kernel
+static int g_gemm_v2 = 1;
 extern "C" void fvhd_debug_set_gemm_v2(int on) { g_gemm_v2 = on; }
+#else
+static constexpr int g_gemm_v2 = 1;
+#endif
 
 template <int EPI, int ODT, int NWV>
 static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,

@@ -251,14 +251,6 @@ def _pack_dw(w):   # [Cout,1,K,K] -> fp32 [K*K][Cout]
 def test_dwconv(K, S, mult, gelu, Cin, H, W, B=2, force_mfma=False):
     lib = _lib.load()
     Cout = Cin * mult
-    if force_mfma:
-        import ctypes
-        raw = ctypes.CDLL(_lib.LIB_PATH)
-        raw.fvhd_debug_set_dw7_cfg(5)          # the matrix-core kernel also below its small-batch threshold
-        try:
-            return test_dwconv(K, S, mult, gelu, Cin, H, W, B)
-        finally:
-            raw.fvhd_debug_set_dw7_cfg(1)
     x = _bf(_rand(B, Cin, H, W, seed=1))
     w = _rand(Cout, 1, K, K, seed=2, scale=1.0 / K)
     b = _rand(Cout, seed=3, scale=0.2)
@@ -266,7 +258,10 @@ def test_dwconv(K, S, mult, gelu, Cin, H, W, B=2, force_mfma=False):
     OH, OW = (H + 2 * (K // 2) - K) // S + 1, (W + 2 * (K // 2) - K) // S + 1
     y = torch.empty(B, OH, OW, Cout, dtype=torch.bfloat16, device=DEV)
     wd, bd = _pack_dw(w).to(DEV), b.to(DEV)
-    _lib.check(lib.fvhd_op_dwconv(_stream(), _p(xn), _p(y), _p(wd), _p(bd), B, H, W, Cin, K, S, mult, gelu), "dwconv")
+    if force_mfma:      # the matrix-core kernel directly, also below the batch size from which fvhd_op_dwconv picks it
+        _lib.check(lib.fvhd_op_dw7_mfma(_stream(), _p(xn), _p(y), _p(wd), _p(bd), B, H, W, Cin), "dw7 mfma")
+    else:
+        _lib.check(lib.fvhd_op_dwconv(_stream(), _p(xn), _p(y), _p(wd), _p(bd), B, H, W, Cin, K, S, mult, gelu), "dwconv")
     torch.cuda.synchronize()
     want = F.conv2d(x.float(), w, b, stride=S, padding=K // 2, groups=Cin)
     if gelu:
@@ -289,6 +284,14 @@ def test_dwconv(K, S, mult, gelu, Cin, H, W, B=2, force_mfma=False):
 def test_dwconv_matrix_core_kernel(Cin, H, W, B, force):
     """dw7x7 stride 1 on the 16-block MFMA (csrc/dwconv_mfma.hip) against the fp32 conv"""
     test_dwconv(7, 1, 1, 0, Cin, H, W, B, force_mfma=force)
+
+
+def test_dw7_mfma_rejects_shapes_it_does_not_take():
+    lib = _lib.load()
+    x = torch.zeros(1, 8, 32, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(49, 64, device=DEV)
+    assert lib.fvhd_op_dw7_mfma(_stream(), _p(x), _p(x), _p(w), None, 1, 8, 32, 64) != 0      # W < 64
+    assert lib.fvhd_op_dw7_mfma(_stream(), _p(x), _p(x), _p(w), None, 1, 8, 64, 32) != 0      # C = 32
 
 
 def test_dwconv_unsupported_channel_count_is_an_error():

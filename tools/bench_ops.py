@@ -17,6 +17,15 @@ DEV = "cuda:0"
 lib = _lib.load()
 
 
+def _knobs():
+    """the kernel-selection setters exist in the debug build only"""
+    raw = C.CDLL(_lib.LIB_PATH)
+    if not hasattr(raw, "fvhd_debug_set_dw7_cfg"):
+        raise SystemExit("this benchmark switches kernels: build the debug library (FVHD_FFN_ABLATE=1 python -m ml_fastvlm_amd.build) "
+                         "and run with FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so")
+    return raw
+
+
 def p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -82,7 +91,7 @@ def ffn_stamps(Cc=192):
     for _ in range(3):
         _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc))
     torch.cuda.synchronize()
-    raw = C.CDLL(_lib.LIB_PATH)
+    raw = _knobs()
     buf = (C.c_uint * (8 * 40 * 4))()
     assert raw.fvhd_debug_ffn_stamps(buf) == 0
     st = np.array(buf, dtype=np.int64).reshape(8, 40, 4)
@@ -115,7 +124,7 @@ def bench_stem(B=32, R=1024):
 
 
 def bench_dw(B=32, modes=(0,)):
-    raw = C.CDLL(_lib.LIB_PATH)
+    raw = _knobs()
     for mode in modes:
         raw.fvhd_debug_set_dw_mode(mode)
         if mode:
@@ -125,7 +134,7 @@ def bench_dw(B=32, modes=(0,)):
 
 
 def bench_dw3cfg():
-    raw = C.CDLL(_lib.LIB_PATH)
+    raw = _knobs()
     for cfg in (0, 1, 2):
         raw.fvhd_debug_set_dw3_cfg(cfg)
         print(f"--- dw3 config {cfg}")
@@ -147,7 +156,7 @@ def bench_dw3cfg():
 
 def bench_dw7cfg():
     """dw7x7 stride 1: 0 = VALU kernel (dwconv.hip), 1 = default dispatch (matrix-core kernel dwconv_mfma.hip where it applies)"""
-    raw = C.CDLL(_lib.LIB_PATH)
+    raw = _knobs()
     for cfg in (0, 1):
         raw.fvhd_debug_set_dw7_cfg(cfg)
         print(f"--- dw7 config {cfg} ({'VALU kernel' if cfg == 0 else 'default dispatch'})")
@@ -198,7 +207,7 @@ def bench_gemm(B=32):
               ("s4 fc1", B * 256, 6144, 1536, 2), ("s4 fc2", B * 256, 1536, 6144, 3),
               ("proj0 H896", B * 256, 896, 3072, 2), ("proj2 H896", B * 256, 896, 896, 1),
               ("proj0 H3584", B * 256, 3584, 3072, 2), ("proj2 H3584", B * 256, 3584, 3584, 1)]
-    raw = C.CDLL(_lib.LIB_PATH)
+    raw = _knobs()
     for v2 in (0, 1):
       raw.fvhd_debug_set_gemm_v2(v2)
       print(f"--- gemm: {('v1 only (128x128, register prefetch)', 'default dispatch (256x128 LDS-DMA ring where it pays)')[v2]}")

@@ -21,6 +21,8 @@ CLASSES = [  # (class, regex on kernel name); first match wins
     ("ffn_fused_c384", r"ffn_(fused|persist\d)_kernelILi384E|ffn_(fused|persist\d)_kernel<384"),
     ("ffn_fused_c192", r"ffn_(fused|persist\d)_kernelILi192E|ffn_(fused|persist\d)_kernel<192"),
     ("ffn_fused_c96", r"ffn_(fused|persist\d)_kernelILi96E|ffn_(fused|persist\d)_kernel<96"),
+    ("dw7_mfma_c64 (C = 192, 384)", r"dw7_mfma_kernelILi4E|dw7_mfma_kernel<4"),
+    ("dw7_mfma_c96 (C = 96)", r"dw7_mfma_kernelILi6E|dw7_mfma_kernel<6"),
     ("dw7_s1", r"dwconv_tiled_kernelILi7ELi1ELi1E|dwconv_tiled_kernel<7, 1, 1"),
     ("dw3_s1", r"dwconv_tiled_kernelILi3ELi1ELi1E|dwconv_tiled_kernel<3, 1, 1"),
     ("dw_mixer_fused", r"dwmix_kernel"),
@@ -29,6 +31,10 @@ CLASSES = [  # (class, regex on kernel name); first match wins
     ("stem", r"stem_(fused|conv)_kernel|dwconv_tiled_kernelILi3ELi2ELi1E"),
     ("attention", r"attention_kernel"),
     ("layernorm", r"layernorm_kernel"),
+    ("gemm_gelu (fc1 / 1x1 / proj0)", r"gemm256_kernel<2,|gemm256_kernelILi2E"),          # streaming kernel: template <EPI, ODT, NWV>
+    ("gemm_resid (fc2 / proj)", r"gemm256_kernel<3,|gemm256_kernelILi3E"),
+    ("gemm_plain (qkv)", r"gemm256_kernel<0,|gemm256_kernelILi0E"),
+    ("gemm_bias (proj2)", r"gemm256_kernel<1,|gemm256_kernelILi1E"),
     ("gemm_gelu (fc1 / 1x1 / proj0)", r"gemm\w*_kernel<\d+, \d+, 2,|gemm\w*_kernelILi\d+ELi\d+ELi2E"),
     ("gemm_resid (fc2 / proj)", r"gemm\w*_kernel<\d+, \d+, 3,|gemm\w*_kernelILi\d+ELi\d+ELi3E"),
     ("gemm_plain (qkv)", r"gemm\w*_kernel<\d+, \d+, 0,|gemm\w*_kernelILi\d+ELi\d+ELi0E"),
@@ -77,7 +83,7 @@ def main():
           "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch cycles), dispatch cycles from GRBM_GUI_ACTIVE when collected (else 2.0 GHz x duration).\n")
     print("| class | dispatches | avg us (trace) | HBM read MB | HBM write MB | HBM GB/s | MFMA busy % | clock GHz | LDS bank-conflict % | wave-cycles: active / issue-stall / waitcnt % |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---|")
-    for cls, _ in CLASSES:
+    for cls in dict.fromkeys(c for c, _ in CLASSES):       # a class may have several patterns: one row
         c = out.get(cls)
         if not c:
             continue
