@@ -184,6 +184,18 @@ int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* hos
 int fvhd_op_ffn_fused(fvhd_stream_t stream, const void* A, const void* w1img, const float* b1, const void* w2img,
                       const float* b2, const float* ls, void* X, int M, int C);
 
+/* Image preprocessing of ONE image on the device - `process_images` / `expand2square` (llava/mm_utils.py:154-184) around the
+ * tower's CLIPImageProcessor (mobileclip_encoder.py:45-49): canvas of the background colour, Pillow's 8-bit bicubic resample
+ * (Resample.c, bit-exact: fixed-point taps with 22 fractional bits, horizontal pass rounded to uint8, then vertical), centre crop,
+ * x * (1/255).  src: uint8 HWC RGB [src_h][src_pitch bytes] sitting at (pad_top, pad_left) of the canvas, bg = 0xBBGGRR.
+ * hbounds / vbounds: int32 [R][2] (first canvas column / row, tap count) and hcoef / vcoef: int32 [R][hk | vk] for the R cropped
+ * output columns / rows (ml_fastvlm_amd/preprocess.py computes them like `precompute_coeffs` + `normalize_coeffs_8bpc`);
+ * tmp: nrows * R * 3 bytes of scratch for the canvas rows [row0, row0 + nrows) the vertical taps touch; lut: 256 floats
+ * (value * scale as the reference rounds it); out: [3][R][R] of out_dtype.  All pointers are device pointers. */
+int fvhd_op_preprocess(fvhd_stream_t stream, const void* src, int src_h, int src_w, int64_t src_pitch, int pad_top, int pad_left,
+                       uint32_t bg, const int32_t* hbounds, const int32_t* hcoef, int hk, const int32_t* vbounds, const int32_t* vcoef,
+                       int vk, int row0, int nrows, void* tmp, const float* lut, int R, void* out, int out_dtype);
+
 /* ---- multimodal embedding splice --------------------------------------------------
  * The data movement of LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal (llava_arch.py:233-332) as one gather:
  * out[b, t] = embedding-table row of a text token, a row of the image features, or zeros (padding), plus attention mask,

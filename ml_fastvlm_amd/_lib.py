@@ -59,6 +59,7 @@ def _declare(lib) -> None:
         "fvhd_op_ffn_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci]),
         "fvhd_ffn_fused_supported": (ci, [ci]),
         "fvhd_ffn_pack": (ci, [ci, vp, vp, vp, vp]),
+        "fvhd_op_preprocess": (ci, [vp, vp, ci, ci, C.c_int64, ci, ci, C.c_uint32, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp, ci, vp, ci]),
         "fvhd_op_splice": (ci, [vp] * 12 + [ci, ci, ci, ci, C.c_int64, C.c_int64, ci, ci]),
     }
     del fp, cl

@@ -17,6 +17,8 @@
 extern "C" {
 int fvhd_launch_dwconv(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int, int, int, int, int);
 int fvhd_launch_dw7_mfma(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int);
+int fvhd_launch_preprocess(hipStream_t, const void*, int, int, long, int, int, unsigned, const int*, const int*, int, const int*, const int*, int, int, int,
+                           void*, const float*, int, void*, int);
 int fvhd_dw7_mfma_supported(int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
@@ -999,6 +1001,17 @@ int fvhd_op_dw7_mfma(fvhd_stream_t st, const void* x, void* y, const float* w, c
                     std::to_string(H) + " W=" + std::to_string(W) + " C=" + std::to_string(C) + ")");
     int e = fvhd_launch_dw7_mfma((hipStream_t)st, x, y, w, bias, B, H, W, C);
     return e ? hip_fail("fvhd_op_dw7_mfma", (hipError_t)e) : 0;
+}
+
+int fvhd_op_preprocess(fvhd_stream_t st, const void* src, int src_h, int src_w, int64_t src_pitch, int pad_top, int pad_left, uint32_t bg,
+                       const int32_t* hbounds, const int32_t* hcoef, int hk, const int32_t* vbounds, const int32_t* vcoef, int vk, int row0,
+                       int nrows, void* tmp, const float* lut, int R, void* out, int out_dtype)
+{
+    if (!src || !hbounds || !hcoef || !vbounds || !vcoef || !tmp || !lut || !out) return fail("fvhd_op_preprocess: NULL pointer");
+    if (src_pitch < 3ll * src_w) return fail("fvhd_op_preprocess: src_pitch smaller than a row of RGB pixels");
+    int e = fvhd_launch_preprocess((hipStream_t)st, src, src_h, src_w, (long)src_pitch, pad_top, pad_left, bg, hbounds, hcoef, hk, vbounds, vcoef,
+                                   vk, row0, nrows, tmp, lut, R, out, out_dtype);
+    return e ? hip_fail("fvhd_op_preprocess", (hipError_t)e) : 0;
 }
 
 int fvhd_op_ffn_fused(fvhd_stream_t st, const void* A, const void* w1img, const float* b1, const void* w2img, const float* b2,

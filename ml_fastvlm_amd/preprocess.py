@@ -1,0 +1,136 @@
+"""Image preprocessing on the GPU - the drop-in for `process_images` (`llava/mm_utils.py:168-184`) with the tower's
+`CLIPImageProcessor` (`mobileclip_encoder.py:45-49`) for the aspect-ratio modes `'pad'` (expand2square, `mm_utils.py:154-165`)
+and the default (plain processor), SURVEY.md 8f-3.  `'anyres'` tiling is not covered (the FastVLM checkpoints use `'pad'`).
+
+Host side (this file): the geometry (square canvas, shortest edge -> R, centre crop) and Pillow's coefficient tables
+(`precompute_coeffs` + `normalize_coeffs_8bpc` of Resample.c, restated in numpy float64 in the same operation order and cached per
+(input size, output size)), restricted to the R x R crop window.  Device side: `fvhd_op_preprocess` (csrc/preprocess.hip) runs
+Pillow's two 8-bit passes and the 1/255 rescale.  The result is bit-identical to the reference's CPU pipeline (tests/
+test_preprocess.py pins the numpy oracle to Pillow / transformers / the reference function, and the kernels to the oracle).
+Images are uint8 HWC RGB tensors ALREADY on the device (a decoded camera frame or a batch staged by the data loader): there is
+no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import math
+from typing import List, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: np.ndarray) -> np.ndarray:
+    a = -0.5
+    x = np.abs(x)
+    near = ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    far = (((x - 5) * x + 8) * x - 4) * a
+    return np.where(x < 1.0, near, np.where(x < 2.0, far, 0.0))
+
+
+@functools.lru_cache(maxsize=64)
+def _coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Pillow's bounds [out][2] and fixed-point taps [out][ksize] for resampling in_size -> out_size (identity when equal: Pillow
+    skips the pass, and a single tap of 1.0 reproduces that exactly)."""
+    if in_size == out_size:
+        b = np.stack([np.arange(out_size), np.ones(out_size, dtype=np.int64)], 1).astype(np.int32)
+        return b, np.full((out_size, 1), 1 << PRECISION_BITS, dtype=np.int32)
+    scale = float(np.float32(in_size) - np.float32(0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xx = np.arange(out_size, dtype=np.float64)
+    center = 0.0 + (xx + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)          # C (int) cast of a non-negative-or-clamped value
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    ss = 1.0 / filterscale
+    x = np.arange(ksize, dtype=np.float64)[None, :]
+    w = _bicubic((x + xmin[:, None] - center[:, None] + 0.5) * ss)
+    w = np.where(x < xmax[:, None], w, 0.0)
+    ww = np.zeros(out_size)
+    for j in range(ksize):                                                   # the C loop's left-to-right accumulation order
+        ww = ww + w[:, j]
+    k = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    v = k * float(1 << PRECISION_BITS)
+    kk = np.where(k < 0, (-0.5 + v), (0.5 + v)).astype(np.int64).astype(np.int32)   # (int) truncates toward zero
+    return np.stack([xmin, xmax], 1).astype(np.int32), kk
+
+
+def _shortest_edge(h: int, w: int, r: int) -> Tuple[int, int]:
+    short, long = (w, h) if w <= h else (h, w)
+    new_short, new_long = r, int(r * long / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+@functools.lru_cache(maxsize=8)
+def _lut(scale: float) -> np.ndarray:
+    return (np.arange(256, dtype=np.float64) * scale).astype(np.float32)     # np_rescale: float64 product rounded to float32
+
+
+class _Plan:
+    """device-resident tables of one (source size, mode, R) geometry"""
+
+    def __init__(self, h: int, w: int, r: int, pad: bool, device):
+        s = max(h, w) if pad else None
+        self.canvas_h, self.canvas_w = (s, s) if pad else (h, w)
+        self.pad_top = (s - h) // 2 if pad and w > h else 0
+        self.pad_left = (s - w) // 2 if pad and h > w else 0
+        nh, nw = _shortest_edge(self.canvas_h, self.canvas_w, r)
+        top, left = (nh - r) // 2, (nw - r) // 2
+        hb, hc = _coeffs(self.canvas_w, nw)
+        vb, vc = _coeffs(self.canvas_h, nh)
+        hb, hc, vb, vc = hb[left:left + r], hc[left:left + r], vb[top:top + r], vc[top:top + r]
+        self.row0 = int(vb[:, 0].min())
+        self.nrows = int((vb[:, 0] + vb[:, 1]).max()) - self.row0
+        self.hk, self.vk = hc.shape[1], vc.shape[1]
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.hb, self.hc, self.vb, self.vc = dev(hb), dev(hc), dev(vb), dev(vc)
+        self.lut = dev(_lut(1 / 255))
+        self.tmp = torch.empty((self.nrows, r, 3), dtype=torch.uint8, device=device)
+
+
+_plans = {}
+
+
+def preprocess_image(image: torch.Tensor, image_size: int, pad: bool = True, dtype: torch.dtype = torch.float32,
+                     out: torch.Tensor = None) -> torch.Tensor:
+    """uint8 [H, W, 3] RGB on a HIP device -> [3, R, R] `dtype` in [0, 1]; `pad` = image_aspect_ratio 'pad' (expand2square with the
+    processor's mean * 255 = black background)."""
+    if image.device.type != "cuda":
+        raise RuntimeError("preprocess_image (MI355X): the image must be on a HIP device - this path has no CPU implementation")
+    if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
+        raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {image.dtype} {tuple(image.shape)}")
+    if image.stride(2) != 1 or image.stride(1) != 3:
+        image = image.contiguous()
+    h, w, r = int(image.shape[0]), int(image.shape[1]), int(image_size)
+    key = (h, w, r, bool(pad), image.device.index)
+    plan = _plans.get(key)
+    if plan is None:
+        if len(_plans) > 32:
+            _plans.clear()
+        plan = _plans[key] = _Plan(h, w, r, bool(pad), image.device)
+    if out is None:
+        out = torch.empty((3, r, r), dtype=dtype, device=image.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(_lib.load().fvhd_op_preprocess(_lib.stream_ptr(image.device), p(image), h, w, image.stride(0), plan.pad_top, plan.pad_left, 0,
+                                              p(plan.hb), p(plan.hc), plan.hk, p(plan.vb), p(plan.vc), plan.vk, plan.row0, plan.nrows,
+                                              p(plan.tmp), p(plan.lut), r, p(out), _lib.dtype_code(out.dtype)), "fvhd_op_preprocess")
+    return out
+
+
+def process_images(images: Sequence[torch.Tensor], image_size: int, image_aspect_ratio: Union[str, None] = "pad",
+                   dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """`mm_utils.process_images` for device-resident uint8 images: returns the stacked [B, 3, R, R] batch."""
+    if image_aspect_ratio == "anyres":
+        raise NotImplementedError("anyres tiling is not part of this path (FastVLM checkpoints use image_aspect_ratio='pad')")
+    if not images:
+        raise ValueError("no images")
+    batch = torch.empty((len(images), 3, image_size, image_size), dtype=dtype, device=images[0].device)
+    for i, im in enumerate(images):
+        preprocess_image(im, image_size, pad=image_aspect_ratio == "pad", dtype=dtype, out=batch[i])
+    return batch

@@ -41,6 +41,7 @@ CLASSES = [  # (class, regex on kernel name); first match wins
     ("gemm_bias (proj2)", r"gemm\w*_kernel<\d+, \d+, 1,|gemm\w*_kernelILi\d+ELi\d+ELi1E"),
     ("se_head", r"se_\w+_kernel"),
     ("splice", r"splice_\w*kernel"),
+    ("preprocess", r"pre_[hv]pass_kernel"),
 ]
 
 
