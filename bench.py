@@ -158,7 +158,13 @@ def cpu_baseline(res: int, hidden: int, budget_s: float = 25.0):
             break
     if best is None:
         return {"value": None, "unit": "images/sec", "cores": avail, "kind": "port", "sample": "every thread count exceeded 8 s per image"}
-    return {"value": round(best[0], 4), "unit": "images/sec", "cores": best[1], "kind": "port",
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), cpu)
+    except OSError:
+        pass
+    return {"value": round(best[0], 4), "unit": "images/sec", "cores": best[1], "kind": "port", "cpu": cpu,
             "sample": f"{best[2]} x (1 image {res}x{res}, fp32, torch CPU oracle of the reference path, best of thread counts "
                       f"<= {avail} logical CPUs; {best[1]} threads used)"}
 
