@@ -1,6 +1,8 @@
 """Image preprocessing on the GPU - the drop-in for `process_images` (`llava/mm_utils.py:168-184`) with the tower's
 `CLIPImageProcessor` (`mobileclip_encoder.py:45-49`) for the aspect-ratio modes `'pad'` (expand2square, `mm_utils.py:154-165`)
-and the default (plain processor), SURVEY.md 8f-3.  `'anyres'` tiling is not covered (the FastVLM checkpoints use `'pad'`).
+the default (plain processor) and `'anyres'` (`process_anyres_image`, `mm_utils.py:121-147`: best grid resolution, aspect-preserving
+resize on a black canvas, S x S patches + the whole image squeezed to S x S), SURVEY.md 8f-3.  The feature-side re-layout of
+anyres patches (`llava_arch.py:165-206`) is host tensor plumbing of the LLM wrapper and not part of this path.
 
 Host side (this file): the geometry (square canvas, shortest edge -> R, centre crop) and Pillow's coefficient tables
 (`precompute_coeffs` + `normalize_coeffs_8bpc` of Resample.c, restated in numpy float64 in the same operation order and cached per
@@ -94,42 +96,128 @@ class _Plan:
         self.tmp = torch.empty((self.nrows, r, 3), dtype=torch.uint8, device=device)
 
 
+class _WindowPlan:
+    """anyres geometry: the image resampled to (res_h, res_w), placed at (off_y, off_x) of a black canvas, window [win_y, +r) x
+    [win_x, +r) of that canvas.  Columns / rows of the window outside the placed image get ZERO taps: the fixed-point sum is then
+    the rounding constant alone and clips to 0 = black, exactly the pasted canvas."""
+
+    def __init__(self, h, w, res_h, res_w, off_y, off_x, win_y, win_x, r, device):
+        def axis(n_in, n_res, off, win):
+            b, k = _coeffs(n_in, n_res)
+            idx = np.arange(win, win + r) - off
+            ok = (idx >= 0) & (idx < n_res)
+            bb = np.zeros((r, 2), dtype=np.int32)
+            kk = np.zeros((r, k.shape[1]), dtype=np.int32)
+            bb[ok], kk[ok] = b[idx[ok]], k[idx[ok]]
+            return bb, kk, ok
+        hb, hc, okx = axis(w, res_w, off_x, win_x)
+        vb, vc, oky = axis(h, res_h, off_y, win_y)
+        self.empty = not (okx.any() and oky.any())
+        if self.empty:
+            return
+        self.pad_top = self.pad_left = 0
+        self.row0 = int(vb[oky, 0].min())
+        self.nrows = int((vb[oky, 0] + vb[oky, 1]).max()) - self.row0
+        vb = vb.copy()
+        vb[~oky, 0] = self.row0                               # empty rows: zero taps, any valid first row
+        self.hk, self.vk = hc.shape[1], vc.shape[1]
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.hb, self.hc, self.vb, self.vc = dev(hb), dev(hc), dev(vb), dev(vc)
+        self.lut = dev(_lut(1 / 255))
+        self.tmp = torch.empty((self.nrows, r, 3), dtype=torch.uint8, device=device)
+
+
 _plans = {}
+
+
+def _run(plan, image, h, w, r, out):
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(_lib.load().fvhd_op_preprocess(_lib.stream_ptr(image.device), p(image), h, w, image.stride(0), plan.pad_top, plan.pad_left, 0,
+                                              p(plan.hb), p(plan.hc), plan.hk, p(plan.vb), p(plan.vc), plan.vk, plan.row0, plan.nrows,
+                                              p(plan.tmp), p(plan.lut), r, p(out), _lib.dtype_code(out.dtype)), "fvhd_op_preprocess")
+
+
+def _check_image(image):
+    if image.device.type != "cuda":
+        raise RuntimeError("preprocess (MI355X): the image must be on a HIP device - this path has no CPU implementation")
+    if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
+        raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {image.dtype} {tuple(image.shape)}")
+    return image if image.stride(2) == 1 and image.stride(1) == 3 else image.contiguous()
+
+
+def _best_resolution(w: int, h: int, candidates) -> Tuple[int, int]:
+    """the grid resolution that keeps most of the image's pixels after an aspect-preserving fit, least padding on ties, first
+    candidate on full ties (`select_best_resolution`, mm_utils.py:14-41)"""
+    best, best_key = None, None
+    for cw, ch in candidates:
+        s = min(cw / w, ch / h)
+        eff = min(int(w * s) * int(h * s), w * h)
+        key = (eff, eff - cw * ch)
+        if best_key is None or key > best_key:
+            best, best_key = (int(cw), int(ch)), key
+    return best
+
+
+def process_anyres_image(image: torch.Tensor, image_size: int, grid_pinpoints, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """uint8 [H, W, 3] on the device -> [1 + patches, 3, S, S]: the whole image squeezed to S x S, then the S x S patches (row-major)
+    of the image fitted into the best grid resolution on a black canvas (`process_anyres_image`, mm_utils.py:121-147)."""
+    image = _check_image(image)
+    if isinstance(grid_pinpoints, str):
+        import ast
+        grid_pinpoints = ast.literal_eval(grid_pinpoints)
+    h, w, s = int(image.shape[0]), int(image.shape[1]), int(image_size)
+    tw, th = _best_resolution(w, h, [tuple(p) for p in grid_pinpoints])
+    sw, sh = tw / w, th / h
+    if sw < sh:
+        nw, nh = tw, min(math.ceil(h * sw), th)
+    else:
+        nh, nw = th, min(math.ceil(w * sh), tw)
+    off_x, off_y = (tw - nw) // 2, (th - nh) // 2
+    windows = [(s, s, 0, 0, 0, 0)] + [(nh, nw, off_y, off_x, i, j) for i in range(0, th, s) for j in range(0, tw, s)]
+    out = torch.empty((len(windows), 3, s, s), dtype=dtype, device=image.device)
+    for n, (rh, rw, oy, ox, wy, wx) in enumerate(windows):
+        key = ("win", h, w, rh, rw, oy, ox, wy, wx, s, image.device.index)
+        plan = _plans.get(key)
+        if plan is None:
+            if len(_plans) > 64:
+                _plans.clear()
+            plan = _plans[key] = _WindowPlan(h, w, rh, rw, oy, ox, wy, wx, s, image.device)
+        if plan.empty:
+            out[n].zero_()
+        else:
+            _run(plan, image, h, w, s, out[n])
+    return out
 
 
 def preprocess_image(image: torch.Tensor, image_size: int, pad: bool = True, dtype: torch.dtype = torch.float32,
                      out: torch.Tensor = None) -> torch.Tensor:
     """uint8 [H, W, 3] RGB on a HIP device -> [3, R, R] `dtype` in [0, 1]; `pad` = image_aspect_ratio 'pad' (expand2square with the
     processor's mean * 255 = black background)."""
-    if image.device.type != "cuda":
-        raise RuntimeError("preprocess_image (MI355X): the image must be on a HIP device - this path has no CPU implementation")
-    if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
-        raise ValueError(f"expected a uint8 [H, W, 3] RGB image, got {image.dtype} {tuple(image.shape)}")
-    if image.stride(2) != 1 or image.stride(1) != 3:
-        image = image.contiguous()
+    image = _check_image(image)
     h, w, r = int(image.shape[0]), int(image.shape[1]), int(image_size)
     key = (h, w, r, bool(pad), image.device.index)
     plan = _plans.get(key)
     if plan is None:
-        if len(_plans) > 32:
+        if len(_plans) > 64:
             _plans.clear()
         plan = _plans[key] = _Plan(h, w, r, bool(pad), image.device)
     if out is None:
         out = torch.empty((3, r, r), dtype=dtype, device=image.device)
-    p = lambda t: C.c_void_p(t.data_ptr())
-    _lib.check(_lib.load().fvhd_op_preprocess(_lib.stream_ptr(image.device), p(image), h, w, image.stride(0), plan.pad_top, plan.pad_left, 0,
-                                              p(plan.hb), p(plan.hc), plan.hk, p(plan.vb), p(plan.vc), plan.vk, plan.row0, plan.nrows,
-                                              p(plan.tmp), p(plan.lut), r, p(out), _lib.dtype_code(out.dtype)), "fvhd_op_preprocess")
+    _run(plan, image, h, w, r, out)
     return out
 
 
 def process_images(images: Sequence[torch.Tensor], image_size: int, image_aspect_ratio: Union[str, None] = "pad",
-                   dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """`mm_utils.process_images` for device-resident uint8 images: returns the stacked [B, 3, R, R] batch."""
-    if image_aspect_ratio == "anyres":
-        raise NotImplementedError("anyres tiling is not part of this path (FastVLM checkpoints use image_aspect_ratio='pad')")
+                   dtype: torch.dtype = torch.float32, grid_pinpoints=None):
+    """`mm_utils.process_images` for device-resident uint8 images: the stacked [B, 3, R, R] batch ('pad' / default) or, for
+    'anyres', the per-image [1 + patches, 3, R, R] tensors stacked when their shapes agree and returned as a list otherwise."""
     if not images:
         raise ValueError("no images")
+    if image_aspect_ratio == "anyres":
+        if grid_pinpoints is None:
+            raise ValueError("image_aspect_ratio='anyres' needs grid_pinpoints (model_cfg.image_grid_pinpoints)")
+        outs = [process_anyres_image(im, image_size, grid_pinpoints, dtype) for im in images]
+        return torch.stack(outs, 0) if all(o.shape == outs[0].shape for o in outs) else outs
     batch = torch.empty((len(images), 3, image_size, image_size), dtype=dtype, device=images[0].device)
     for i, im in enumerate(images):
         preprocess_image(im, image_size, pad=image_aspect_ratio == "pad", dtype=dtype, out=batch[i])

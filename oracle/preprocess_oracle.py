@@ -128,3 +128,43 @@ def preprocess(img: np.ndarray, r: int, pad: bool) -> np.ndarray:
     top, left = (nh - r) // 2, (nw - r) // 2
     crop = res[top:top + r, left:left + r]
     return (crop.astype(np.float64) * (1 / 255)).astype(np.float32).transpose(2, 0, 1)
+
+
+# ---- anyres (`llava/mm_utils.py:14-147`): best grid resolution, aspect-preserving resize pasted on a black canvas, S x S patches,
+# ---- plus the whole image squeezed to S x S; every patch then goes through the processor (a no-op resize / crop at S x S)
+def select_best_resolution(size_wh, candidates):
+    w, h = size_wh
+    best, best_eff, best_waste = None, 0, float("inf")
+    for cw, ch in candidates:                                   # mm_utils.py:31-40
+        s = min(cw / w, ch / h)
+        eff = min(int(w * s) * int(h * s), w * h)
+        waste = cw * ch - eff
+        if eff > best_eff or (eff == best_eff and waste < best_waste):
+            best, best_eff, best_waste = (cw, ch), eff, waste
+    return best
+
+
+def resize_and_pad(img: np.ndarray, target_wh) -> np.ndarray:
+    h, w, _ = img.shape
+    tw, th = target_wh
+    sw, sh = tw / w, th / h                                     # mm_utils.py:57-66
+    if sw < sh:
+        nw, nh = tw, min(math.ceil(h * sw), th)
+    else:
+        nh, nw = th, min(math.ceil(w * sh), tw)
+    res = resize_bicubic_u8(img, nh, nw)                        # Image.resize default filter for RGB: BICUBIC
+    out = np.zeros((th, tw, 3), dtype=np.uint8)
+    px, py = (tw - nw) // 2, (th - nh) // 2
+    out[py:py + nh, px:px + nw] = res
+    return out
+
+
+def preprocess_anyres(img: np.ndarray, r: int, grid_pinpoints) -> np.ndarray:
+    """HWC uint8 -> [1 + patches, 3, r, r] float32 (`process_anyres_image`, mm_utils.py:121-147)"""
+    h, w, _ = img.shape
+    padded = resize_and_pad(img, select_best_resolution((w, h), [tuple(p) for p in grid_pinpoints]))
+    tiles = [resize_bicubic_u8(img, r, r)]
+    for i in range(0, padded.shape[0], r):                      # divide_to_patches: row-major
+        for j in range(0, padded.shape[1], r):
+            tiles.append(padded[i:i + r, j:j + r])
+    return np.stack([(t.astype(np.float64) * (1 / 255)).astype(np.float32).transpose(2, 0, 1) for t in tiles])

@@ -86,5 +86,34 @@ def test_hip_process_images_batch_and_strided_source():
     dev = [torch.from_numpy(imgs[0]).cuda(), big[:, :130], torch.from_numpy(imgs[2]).cuda()]          # the second one is a view with a row pitch
     got = PP.process_images(dev, 64, "pad")
     assert got.shape == (3, 3, 64, 64) and np.array_equal(got.cpu().numpy(), want)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="grid_pinpoints"):
         PP.process_images(dev, 64, "anyres")
+
+
+GRIDS = [[64, 128], [128, 64], [128, 128], [192, 64], [64, 192]]            # (width, height), multiples of the 64-px patch
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="reference tree not mounted")
+@pytest.mark.parametrize("h,w", [(100, 150), (150, 100), (64, 64), (37, 153), (300, 90), (128, 128)])
+def test_oracle_anyres_is_the_reference(h, w):
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    ref_import.import_reference()
+    from llava.mm_utils import process_anyres_image, select_best_resolution
+    ip = CLIPImageProcessor(crop_size={"height": 64, "width": 64}, image_mean=[0.0, 0.0, 0.0], image_std=[1.0, 1.0, 1.0], size={"shortest_edge": 64})
+    a = _img(h, w, 11 * h + w)
+    want = process_anyres_image(Image.fromarray(a), ip, str(GRIDS)).numpy()
+    got = O.preprocess_anyres(a, 64, GRIDS)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert PP._best_resolution(w, h, [tuple(g) for g in GRIDS]) == tuple(select_best_resolution((w, h), [tuple(g) for g in GRIDS]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", [(100, 150), (150, 100), (64, 64), (37, 153), (300, 90), (500, 700)])
+def test_hip_anyres_equals_the_oracle_bit_for_bit(h, w):
+    a = _img(h, w, 13 * h + w)
+    want = O.preprocess_anyres(a, 64, GRIDS)
+    got = PP.process_anyres_image(torch.from_numpy(a).cuda(), 64, str(GRIDS))
+    assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
+    both = PP.process_images([torch.from_numpy(a).cuda()] * 2, 64, "anyres", grid_pinpoints=GRIDS)
+    assert both.shape == (2,) + want.shape
