@@ -150,7 +150,7 @@ int fvhd_op_dwconv(fvhd_stream_t stream, const void* x, void* y, const float* w,
 /* The 7x7 stride-1 depthwise conv (+ bias) on the matrix cores (csrc/dwconv_mfma.hip: 16-block 4x4x4 bf16 MFMA, taps rounded to
  * bf16, fp32 accumulation) for ANY batch size - fvhd_op_dwconv / the tower take this kernel by themselves once the launch fills
  * the chip (or always, under fvhd_set_batch_invariant).  Same arguments as fvhd_op_dwconv(K = 7, stride 1, mult 1, no GELU);
- * needs C % 64 == 0 or C % 96 == 0 and W >= 64, anything else is an error. */
+ * needs C % 64 == 0 or C % 96 == 0 and W >= 16, anything else is an error. */
 int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
 /* out[M,N] = epi(A[M,K] . Wt[N,K]^T): A, Wt, resid bf16; bias, ls fp32 [N]; K % 32 == 0, N % 16 == 0. */
 int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, const float* ls,

@@ -14,7 +14,7 @@
 // axis is contiguous: one lane owns 8 output channels (16 B of bf16).  Two kernels:
 //   * dwconv_tiled_kernel (below): LDS-staged input tiles, taps in LDS, strips of 4-8 output pixels per lane - every shape;
 //   * dw7_mfma_kernel (dwconv_mfma.hip): the 7x7 stride-1 case on the 16-block 4x4x4 MFMA, taken by fvhd_launch_dwconv
-//     wherever the map is at least one 64-px strip wide and the channels come in whole 128-B / 192-B pixels.
+//     wherever the map is at least 24 px wide and the channels come in whole 128-B / 192-B pixels (and the launch fills the chip).
 #include "fvhd_common.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -312,7 +312,7 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // dw7x7 stride 1 (46 launches, VALU-bound): 32-channel slices, 4-pixel strips, 32x8 tiles -> 43 KB LDS and <= 170
     // VGPRs, i.e. 3 workgroups (12 waves) per CU instead of 2: a wave64 VALU instruction issues every ~4 cycles per wave
     // but executes in ~2.3, so the pipe only saturates with >= 3 waves per SIMD (tools/ubench/valu_rate.hip)
-    // dw7x7 stride 1 on the matrix cores (dwconv_mfma.hip) wherever the map is at least one 64-px strip wide and the channels
+    // dw7x7 stride 1 on the matrix cores (dwconv_mfma.hip) wherever the map is at least 24 px wide and the channels
     // come in whole 128-B lines: 109 / 60 us at C = 192 / 384 (B = 32, 1024^2 input) against 246 / 118 for the VALU kernel
     // below, which stays for C = 96, narrow maps and as the comparison path (debug build: fvhd_debug_set_dw7_cfg(0)).
     if (K == 7 && stride == 1 && mult == 1 && !gelu && g_dw7_cfg != 0 && fvhd_dw7_mfma_supported(B, H, W, Cin, batch_invariant || g_dw7_cfg == 5))

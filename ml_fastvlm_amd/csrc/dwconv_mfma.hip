@@ -336,8 +336,11 @@ static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, co
 // 1 = this kernel takes the shape (the caller falls back to the VALU kernel otherwise); force: ignore the small-batch rule (tests)
 extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force)
 {
-    if (!((C % 64 == 0 || C % 96 == 0) && W >= 64 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
-    return force || dwm_rows_per_chunk(B, H, W, C) > 0;
+    if (!((C % 64 == 0 || C % 96 == 0) && W >= 16 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
+    if (force) return 1;
+    // narrower maps run the same 64-px strip with masked columns: still ahead of the VALU kernel down to W = 24 (B = 32, C = 768 @32x32:
+    // 54 vs 62 us; 48x48: 57 vs 83; C = 1536 @24x24: 42 vs 53), behind it at W = 16 (47 vs 34: three quarters of the strip is padding)
+    return W >= 24 && dwm_rows_per_chunk(B, H, W, C) > 0;
 }
 
 // x, y [B, H, W, C] bf16 (NHWC); w fp32 [49][C]; bias fp32 [C] or null

@@ -997,7 +997,7 @@ int fvhd_op_dw7_mfma(fvhd_stream_t st, const void* x, void* y, const float* w, c
 {
     if (!x || !y || !w) return fail("fvhd_op_dw7_mfma: NULL pointer");
     if (!fvhd_dw7_mfma_supported(B, H, W, C, 1))
-        return fail("fvhd_op_dw7_mfma: needs C % 64 == 0 or C % 96 == 0, W >= 64 and an image below 2 GiB (got B=" + std::to_string(B) + " H=" +
+        return fail("fvhd_op_dw7_mfma: needs C % 64 == 0 or C % 96 == 0, W >= 16 and an image below 2 GiB (got B=" + std::to_string(B) + " H=" +
                     std::to_string(H) + " W=" + std::to_string(W) + " C=" + std::to_string(C) + ")");
     int e = fvhd_launch_dw7_mfma((hipStream_t)st, x, y, w, bias, B, H, W, C);
     return e ? hip_fail("fvhd_op_dw7_mfma", (hipError_t)e) : 0;

@@ -278,6 +278,9 @@ def test_dwconv(K, S, mult, gelu, Cin, H, W, B=2, force_mfma=False):
     (96, 40, 128, 2, True),      # 96-channel workgroups (6 waves): stage 1
     (96, 37, 70, 3, True),       # ... ragged strip and chunk
     (192, 5, 256, 2, True),      # 96 would also divide 192: the 64-channel path is taken
+    (128, 32, 32, 2, True),      # narrower than a strip: masked columns (stage 4 of the 1024^2 tower)
+    (64, 24, 40, 3, True),
+    (64, 9, 16, 2, True),        # the narrowest map the kernel accepts
     (192, 64, 64, 24, False),    # large enough to take the kernel by itself, 16-row chunks
     (64, 96, 128, 40, False),    # ... 32-row chunks
 ])
@@ -290,7 +293,7 @@ def test_dw7_mfma_rejects_shapes_it_does_not_take():
     lib = _lib.load()
     x = torch.zeros(1, 8, 32, 64, dtype=torch.bfloat16, device=DEV)
     w = torch.zeros(49, 64, device=DEV)
-    assert lib.fvhd_op_dw7_mfma(_stream(), _p(x), _p(x), _p(w), None, 1, 8, 32, 64) != 0      # W < 64
+    assert lib.fvhd_op_dw7_mfma(_stream(), _p(x), _p(x), _p(w), None, 1, 8, 8, 64) != 0       # W < 16
     assert lib.fvhd_op_dw7_mfma(_stream(), _p(x), _p(x), _p(w), None, 1, 8, 64, 32) != 0      # C = 32
 
 
