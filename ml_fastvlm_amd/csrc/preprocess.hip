@@ -84,7 +84,7 @@ extern "C" int fvhd_launch_preprocess(hipStream_t st, const void* src, int src_h
 {
     if (R <= 0 || nrows <= 0 || hk <= 0 || vk <= 0 || src_h <= 0 || src_w <= 0) return (int)hipErrorInvalidValue;
     const dim3 g1((R + 255) / 256, nrows), g2((R + 255) / 256, R);
-    if (g1.y > 65535u * 1024u || g2.y > 65535u * 1024u) return (int)hipErrorInvalidValue;
+    if (g1.y > 65535u || g2.y > 65535u) return (int)hipErrorInvalidValue;      // grid.y limit: images taller than 65535 rows are not a camera format
     hipLaunchKernelGGL(pre_hpass_kernel, g1, dim3(256), 0, st, (const unsigned char*)src, src_h, src_w, src_pitch, pad_top, pad_left, bg,
                        hb, hc, hk, row0, nrows, R, (unsigned char*)tmp);
     if (out_dtype == FVHD_F32)
