@@ -537,7 +537,9 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
     const int n = (int)c->m.steps.size();
     // profiling brackets single launches with events: keep them on one stream, un-overlapped
-    const bool dualmode = c->dual && B >= 2 && !c->prof;
+    // two half-batches on two streams pay from ~12 images on (B = 16: 13.40 vs 13.78 ms; B = 32: +0.4 %); below that the halves
+    // no longer fill the chip and fall under the small-batch kernel thresholds (B = 8: 8.25 vs 7.75 ms single-stream)
+    const bool dualmode = c->dual && B >= 12 && !c->prof;
     if (dualmode && !c->aux) {
         hipError_t he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
