@@ -17,15 +17,20 @@
 //   * a WAVE owns 16 channels x a 64-px strip and marches down the rows of its chunk with 7 live output rows in registers
 //     (112 accumulator VGPRs): every input row is read once and feeds 7 x 12 = 84 MFMAs; the row loop is unrolled 7x so the
 //     slot of an output row is a compile-time register index;
-//   * a WORKGROUP = 4 waves = 4 adjacent channel groups = 64 channels = one whole 128-B line per pixel: the input row
-//     segment arrives by LDS-DMA as whole lines in a ring of RS raw rows shared by the workgroup (each wave issues 2 of the 8
-//     interior 1-KiB pieces and a quarter of the halo piece; no VGPRs, RS - 1 rows in flight behind a counted vmcnt), each wave
-//     transposes ITS 32-B column of every pixel into a private [channel][pixel] image (the A operand needs pixels of one
-//     channel adjacent in a lane; NHWC has channels adjacent - this transposition, ds_read_b128 -> 8 ds_write_b16, is the price
-//     of running a depthwise conv on MFMA), and the finished output row is assembled in a shared [pixel][64 ch] buffer and
-//     leaves as whole lines (2 stores of 1 KiB per wave).  Per-lane 32-B segments instead (one wave = its own I/O) measured
-//     3.3 TB/s of mixed traffic against 4.9 TB/s for whole lines;
-//   * one s_barrier per row; columns outside the image stay zero in the transposed image, rows outside are never read.
+//   * a WORKGROUP = 4 waves = 4 adjacent channel groups = 64 channels = one whole 128-B line per pixel (6 waves = 96 channels
+//     when C is a multiple of 96 only: with C = 96 the row segment of a strip is one contiguous run): the input row segment
+//     arrives by LDS-DMA as whole lines in a ring of RS raw rows shared by the workgroup (each wave issues 2 of the 2 NW
+//     interior 1-KiB pieces and 16 lanes of the halo pixels; no VGPRs, RS - 2 later rows in flight behind a counted vmcnt),
+//     each wave transposes ITS 32-B column of every pixel into a private double-buffered [channel][pixel] image (the A operand
+//     needs pixels of one channel adjacent in a lane; NHWC has channels adjacent - this transposition, ds_read_b128 -> 8
+//     ds_write_b16, is the price of running a depthwise conv on MFMA), and the finished output row is assembled in a shared
+//     [pixel][channel] buffer and leaves as whole lines (2 stores of 1 KiB per wave), one iteration later.  Per-lane 32-B
+//     segments instead (one wave = its own I/O) measured 3.3 TB/s of mixed traffic against 4.9 TB/s for whole lines;
+//   * one s_barrier per row; inside an iteration every non-MFMA instruction of the row (transposing writes, A reads, stores,
+//     the next DMA, conversions, staging writes) sits behind a fixed MFMA of the 84 - one per MFMA, an 8-cycle MFMA leaves one
+//     issue slot - so a wave overlaps its own LDS / memory work with its matrix work;
+//   * columns outside the image stay zero in the transposed image (maps narrower than a strip run with masked columns), rows
+//     outside are never read; rows per chunk shrink with the batch (dwm_rows_per_chunk) so small launches still fill the chip.
 // Hand-pinned hazards (the compiler does not know the asm statements are MFMAs): see the comments at the asm statements.
 #include "fvhd_common.h"
 
