@@ -59,6 +59,59 @@ def test_vectorised_coefficients_equal_the_scalar_restatement(n_in, n_out):
     assert np.array_equal(b, ob) and np.array_equal(k, ok)
 
 
+def _emulate_kernels(plan, img, r):
+    """numpy stand-in for csrc/preprocess.hip driven by the product's device tables (on CPU tensors here): same two integer passes"""
+    h, w, _ = img.shape
+    hb, hc, vb, vc = (t.numpy() for t in (plan.hb, plan.hc, plan.vb, plan.vc))
+    tmp = np.zeros((plan.nrows, r, 3), dtype=np.int64)
+    for j in range(plan.nrows):
+        sy = plan.row0 + j - plan.pad_top
+        for xx in range(r):
+            x0, n = hb[xx]
+            acc = np.full(3, 1 << 21, dtype=np.int64)
+            for x in range(n):
+                sx = x0 + x - plan.pad_left
+                px = img[sy, sx].astype(np.int64) if 0 <= sy < h and 0 <= sx < w else np.zeros(3, dtype=np.int64)
+                acc += px * int(hc[xx, x])
+            tmp[j, xx] = np.clip(acc >> 22, 0, 255)
+    out = np.zeros((3, r, r), dtype=np.float32)
+    lut = plan.lut.numpy()
+    for yy in range(r):
+        y0, n = vb[yy]
+        acc = np.full((r, 3), 1 << 21, dtype=np.int64)
+        for y in range(n):
+            acc += tmp[y0 - plan.row0 + y] * int(vc[yy, y])
+        out[:, yy, :] = lut[np.clip(acc >> 22, 0, 255)].T
+    return out
+
+
+@pytest.mark.parametrize("h,w,r,pad", [(40, 60, 16, True), (60, 40, 16, True), (40, 60, 16, False), (16, 16, 16, True), (9, 30, 24, True)])
+def test_plan_tables_reproduce_the_oracle_on_cpu(h, w, r, pad):
+    """host logic without a GPU: canvas offsets, crop windows and coefficient slices of `_Plan`, run through a numpy emulation of
+    the two kernels, give the oracle's bits"""
+    a = _img(h, w, 17 * h + w)
+    plan = PP._Plan(h, w, r, pad, torch.device("cpu"))
+    assert np.array_equal(_emulate_kernels(plan, a, r), O.preprocess(a, r, pad=pad))
+
+
+@pytest.mark.parametrize("h,w", [(40, 60), (60, 25), (16, 16)])
+def test_anyres_window_plans_reproduce_the_oracle_on_cpu(h, w):
+    import math
+    a = _img(h, w, 19 * h + w)
+    s, grids = 16, [[16, 32], [32, 16], [32, 32], [48, 16]]
+    want = O.preprocess_anyres(a, s, grids)
+    tw, th = PP._best_resolution(w, h, [tuple(g) for g in grids])
+    sw, sh = tw / w, th / h
+    nw, nh = (tw, min(math.ceil(h * sw), th)) if sw < sh else (min(math.ceil(w * sh), tw), th)
+    ox, oy = (tw - nw) // 2, (th - nh) // 2
+    windows = [(s, s, 0, 0, 0, 0)] + [(nh, nw, oy, ox, i, j) for i in range(0, th, s) for j in range(0, tw, s)]
+    assert len(windows) == want.shape[0]
+    for n, (rh, rw, py, px, wy, wx) in enumerate(windows):
+        plan = PP._WindowPlan(h, w, rh, rw, py, px, wy, wx, s, torch.device("cpu"))
+        got = np.zeros((3, s, s), dtype=np.float32) if plan.empty else _emulate_kernels(plan, a, s)
+        assert np.array_equal(got, want[n]), n
+
+
 def test_no_cpu_path():
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         PP.preprocess_image(torch.zeros(8, 8, 3, dtype=torch.uint8), 64)
