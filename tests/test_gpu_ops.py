@@ -289,6 +289,17 @@ def test_dwconv_matrix_core_kernel(Cin, H, W, B, force):
     test_dwconv(7, 1, 1, 0, Cin, H, W, B, force_mfma=force)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_dwconv_matrix_core_kernel_random_shapes(seed):
+    """seeded random geometry: any height, widths from the narrowest accepted map to several strips with a ragged last one,
+    both workgroup widths, batch 1..3 (row chunks of 8)"""
+    import random
+    rnd = random.Random(1000 + seed)
+    Cin = rnd.choice([64, 96, 128, 192, 288])
+    H, W, B = rnd.randint(1, 70), rnd.randint(16, 150), rnd.randint(1, 3)
+    test_dwconv(7, 1, 1, 0, Cin, H, W, B, force_mfma=True)
+
+
 def test_dw7_mfma_rejects_shapes_it_does_not_take():
     lib = _lib.load()
     x = torch.zeros(1, 8, 32, 64, dtype=torch.bfloat16, device=DEV)
