@@ -112,6 +112,16 @@ def test_gemm_epilogues(M, N, K, epi):
     _close(got, y, what=f"gemm {M}x{N}x{K} epi{epi}")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_gemm_streaming_kernel_random_shapes(seed):
+    """seeded random shapes inside the streaming kernel's domain (M % 256 == 0, N % 128 == 0, K % 64 == 0, >= 512 tiles), every epilogue"""
+    import random
+    rnd = random.Random(500 + seed)
+    N, K = 128 * rnd.randint(1, 12), 64 * rnd.randint(2, 20)
+    M = 256 * max(rnd.randint(1, 6), -(-512 // (N // 128)))
+    test_gemm_epilogues(M, N, K, rnd.choice([_lib.EPI_NONE, _lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_BIAS_LS_RESID]))
+
+
 def test_gemm_inplace_residual_and_f32_out():
     M, N, K = 200, 384, 1536
     A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
