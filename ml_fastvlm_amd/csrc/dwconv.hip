@@ -253,15 +253,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // (`FVHD_FFN_ABLATE=1 python -m ml_fastvlm_amd.build` -> libfvhd_ablate.so, -DFVHD_DEBUG_KNOBS; tools/bench_ops.py uses it for A/B runs).
 //   dw7 cfg: 0 = never the matrix-core kernel (VALU kernel with the per-C choice), 5 = the matrix-core kernel also below its
 //            small-batch threshold, 1 = default dispatch, 3 = VALU: always 64-channel slices / 8-pixel strips, other = always 32 / 4
-//   dw3 cfg: 0 = register-prefetch tiles (64|32-channel slices, 8-pixel strips), 1/2 = LDS-DMA double buffer, 32/64-channel slices
+//   dw3 cfg: -1 = per-C choice, 0 = register-prefetch tiles (64|32-channel slices, 8-pixel strips), 1/2 = LDS-DMA double buffer, 32/64-channel slices
 //   dw mode: 1 = stage + store only (no tap loop), 2 = no staging loads (tap loop on stale LDS)
 #ifdef FVHD_DEBUG_KNOBS
-static int g_dw7_cfg = 1, g_dw3_cfg = 0, g_dw_mode = 0;
+static int g_dw7_cfg = 1, g_dw3_cfg = -1, g_dw_mode = 0;
 extern "C" void fvhd_debug_set_dw7_cfg(int m) { g_dw7_cfg = m; }
 extern "C" void fvhd_debug_set_dw3_cfg(int m) { g_dw3_cfg = m; }
 extern "C" void fvhd_debug_set_dw_mode(int m) { g_dw_mode = m; }
 #else
-static constexpr int g_dw7_cfg = 1, g_dw3_cfg = 0, g_dw_mode = 0;
+static constexpr int g_dw7_cfg = 1, g_dw3_cfg = -1, g_dw_mode = 0;
 #endif
 
 template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, int PREF = 1>
@@ -329,9 +329,14 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
         if (wide) return (int)launch_dw_tiled<7, 1, 1, false, 64, false, 2, 0>(st, xi, yo, w, bias, B, H, W, Cin);
         return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 3, 0>(st, xi, yo, w, bias, B, H, W, Cin);
     }
-    if (K == 3 && stride == 1 && mult == 1 && !gelu && c32 && g_dw3_cfg) {
-        if (g_dw3_cfg == 2 && c64) return (int)launch_dw_tiled<3, 1, 1, false, 64, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
-        return (int)launch_dw_tiled<3, 1, 1, false, 32, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
+    // RepMixer dw3x3: from C = 192 on the LDS-DMA double-buffered tiles with 64-channel slices (whole 128-B lines per pixel) win
+    // over the register-prefetch tiles - 99.7 -> 87.0 / 42.1 -> 37.4 us at C = 192 / 384 (B = 32), 42.0 -> 37.4 / 26.5 -> 21.9 us for
+    // the half-batches the tower launches: 4.6-5.4 TB/s; at C = 96 (192-B pixels) the two tie and the register version stays.
+    // Same arithmetic order: bit-identical outputs (tools/bench_ops.py dw3cfg, profiles/r02_dw3cfg.log).
+    if (K == 3 && stride == 1 && mult == 1 && !gelu && c32 && g_dw3_cfg != 0) {
+        const int cfg3 = g_dw3_cfg > 0 ? g_dw3_cfg : (c64 && Cin >= 192 ? 2 : 0);
+        if (cfg3 == 2 && c64) return (int)launch_dw_tiled<3, 1, 1, false, 64, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
+        if (cfg3 != 0) return (int)launch_dw_tiled<3, 1, 1, false, 32, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
     }
 #define DW_TILED(KK, SS, MM, AA)                                                                          \
     if (K == KK && stride == SS && mult == MM && (gelu != 0) == AA && c32) {                              \

@@ -135,10 +135,11 @@ def bench_dw(B=32, modes=(0,)):
 
 def bench_dw3cfg():
     raw = _knobs()
-    for cfg in (0, 1, 2):
-        raw.fvhd_debug_set_dw3_cfg(cfg)
-        print(f"--- dw3 config {cfg}")
-        _bench_dw(32, only_k3=True)
+    for B in (32, 16):                         # 16 = the half-batch one stream sees inside fvhd_encode at B = 32
+        for cfg in (0, 2):
+            raw.fvhd_debug_set_dw3_cfg(cfg)
+            print(f"--- dw3 config {cfg}, B = {B}")
+            _bench_dw(B, only_k3=True)
     for Cc, H, B in ((96, 37, 3), (192, 20, 2), (384, 64, 2), (768, 9, 5), (96, 256, 2)):
         x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
         w = torch.randn(9, Cc, device=DEV)
@@ -151,7 +152,7 @@ def bench_dw3cfg():
             torch.cuda.synchronize()
             outs.append(y.clone())
         print(f"dw3 cfg agreement C={Cc} H={H} B={B}:", [bool(torch.equal(outs[0], o)) for o in outs[1:]])
-    raw.fvhd_debug_set_dw3_cfg(0)
+    raw.fvhd_debug_set_dw3_cfg(-1)
 
 
 def bench_dw7cfg():
