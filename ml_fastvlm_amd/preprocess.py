@@ -2,7 +2,7 @@
 `CLIPImageProcessor` (`mobileclip_encoder.py:45-49`) for the aspect-ratio modes `'pad'` (expand2square, `mm_utils.py:154-165`)
 the default (plain processor) and `'anyres'` (`process_anyres_image`, `mm_utils.py:121-147`: best grid resolution, aspect-preserving
 resize on a black canvas, S x S patches + the whole image squeezed to S x S), SURVEY.md 8f-3.  The feature-side re-layout of
-anyres patches (`llava_arch.py:165-206`) is host tensor plumbing of the LLM wrapper and not part of this path.
+anyres patches (`llava_arch.py:165-206`) is `ml_fastvlm_amd.splice.merge_patch_features`.
 
 Host side (this file): the geometry (square canvas, shortest edge -> R, centre crop) and Pillow's coefficient tables
 (`precompute_coeffs` + `normalize_coeffs_8bpc` of Resample.c, restated in numpy float64 in the same operation order and cached per

@@ -97,3 +97,58 @@ def multimodal_splice(input_ids: torch.Tensor, position_ids: Optional[torch.Tens
     new_mask = None if attention_mask is None else mask_out.to(attention_mask.dtype)      # llava_arch.py:325-328
     new_pos = None if position_ids is None else pos_out.to(position_ids.dtype)            # :330-331
     return None, new_pos, new_mask, None, out, lab_out
+
+
+def _unpad_window(cur_h: int, cur_w: int, orig_w: int, orig_h: int):
+    """rows / columns of a [cur_h, cur_w] feature map that hold the image when an orig_w x orig_h picture was fitted into it with
+    its aspect ratio kept and centred (`unpad_image`, llava_arch.py:100-128): (row slice, column slice)"""
+    if orig_w / orig_h > cur_w / cur_h:                 # the picture is wider than the map: bars above and below
+        new_h = int(orig_h * (cur_w / orig_w))
+        pad = (cur_h - new_h) // 2
+        return slice(pad, cur_h - pad), slice(0, cur_w)
+    new_w = int(orig_w * (cur_h / orig_h))
+    pad = (cur_w - new_w) // 2
+    return slice(0, cur_h), slice(pad, cur_w - pad)
+
+
+def merge_patch_features(features: Sequence[torch.Tensor], image_sizes, merge_type: str = "flat", grid_pinpoints=None,
+                         image_size: int = 1024, image_newline: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """Feature-side half of anyres (`llava_arch.py:165-206`): per image, the [1 + patches, T, H] tokens of the squeezed picture and
+    of its grid patches become ONE token sequence - 'flat': plain concatenation; 'spatial': the patch maps are laid out as one
+    big [rows, cols] map after the base image's tokens; 'spatial_unpad': the big map is cropped to the picture (the bars the
+    black canvas added carry no image) and every row gets the learned `image_newline` token appended.  Plain tensor views and
+    copies on whatever device the features live on - no kernel: this is re-layout, not arithmetic.
+    image_sizes: (width, height) of every original picture."""
+    if merge_type == "flat":
+        return [f.flatten(0, 1) for f in features]
+    if not merge_type.startswith("spatial"):
+        raise ValueError(f"Unexpected mm_patch_merge_type: {merge_type}")
+    unpad = "unpad" in merge_type
+    if unpad and image_newline is None:
+        raise ValueError("mm_patch_merge_type with 'unpad' needs the model's image_newline parameter")
+    from .preprocess import _best_resolution
+    out = []
+    for f, (ow, oh) in zip(features, image_sizes):
+        if f.shape[0] == 1:                              # a single tile: its tokens (+ one newline token)
+            g = f[0]
+            out.append(torch.cat([g, image_newline[None].to(g.device, g.dtype)], 0) if unpad else g)
+            continue
+        if grid_pinpoints is None:
+            raise NotImplementedError("spatial merge of several tiles is defined for image_aspect_ratio='anyres' only")
+        if isinstance(grid_pinpoints, str):
+            import ast
+            grid_pinpoints = ast.literal_eval(grid_pinpoints)
+        base, tiles = f[0], f[1:]
+        side, hid = int(round(base.shape[0] ** 0.5)), base.shape[-1]
+        if side * side != base.shape[0]:
+            raise ValueError(f"{base.shape[0]} tokens per tile is not a square map")
+        bw, bh = _best_resolution(int(ow), int(oh), [tuple(p) for p in grid_pinpoints])
+        gw, gh = bw // image_size, bh // image_size
+        big = tiles.reshape(gh, gw, side, side, hid).permute(0, 2, 1, 3, 4).reshape(gh * side, gw * side, hid)
+        if unpad:
+            rows, cols = _unpad_window(gh * side, gw * side, int(ow), int(oh))
+            big = big[rows, cols]
+            nl = image_newline.to(big.device, big.dtype).expand(big.shape[0], 1, hid)
+            big = torch.cat([big, nl], 1)
+        out.append(torch.cat([base, big.reshape(-1, hid)], 0))
+    return out
