@@ -5,7 +5,9 @@ the MI355X tower into an unmodified checkout of apple/ml-fastvlm.
 * `build_vision_projector`  <-> `llava/model/multimodal_projector/builder.py:17-35`
 * `encode_images`           <-> `LlavaMetaForCausalLM.encode_images`, `llava/model/llava_arch.py:141-144`
 * `install_into_llava()`    patches the two names `llava_arch.py` imported (`llava_arch.py:22-23`)
-  so `LlavaMetaModel.__init__` (`llava_arch.py:34-36`) builds our tower; see INTEGRATION.md.
+  so `LlavaMetaModel.__init__` (`llava_arch.py:34-36`) builds our tower, and - with `splice=True` -
+  replaces `prepare_inputs_labels_for_multimodal` (`llava_arch.py:146-332`) by the anyres feature merge
+  + ONE splice kernel of `ml_fastvlm_amd/splice.py`; see INTEGRATION.md.
 """
 from __future__ import annotations
 
@@ -74,8 +76,9 @@ def encode_images(vision_tower, mm_projector, images):
     return mm_projector(image_features)
 
 
-def install_into_llava() -> None:
-    """Make an unmodified `llava` package (the reference) build and call the MI355X tower."""
+def install_into_llava(splice: bool = False) -> None:
+    """Make an unmodified `llava` package (the reference) build and call the MI355X tower; splice=True also routes
+    `prepare_inputs_labels_for_multimodal` through the GPU splice (needs the embeddings on a HIP device)."""
     import llava.model.llava_arch as arch
     import llava.model.multimodal_encoder.builder as enc_builder
 
@@ -94,3 +97,36 @@ def install_into_llava() -> None:
         return encode_images(self.get_model().get_vision_tower(), self.get_model().mm_projector, images)
 
     arch.LlavaMetaForCausalLM.encode_images = _encode_images
+    if splice:
+        arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal = prepare_inputs_labels_for_multimodal
+
+
+def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, image_sizes=None):
+    """Same contract as `LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal` (`llava_arch.py:146-332`): the early outs, the
+    list / 5-D image branch with its patch merge, then the embedding splice - as one gather kernel instead of the per-sample
+    Python walk.  `self` is the reference's model object (it provides `get_vision_tower`, `encode_images`, `get_model`, `config`)."""
+    from . import splice as S
+    vision_tower = self.get_vision_tower()
+    if vision_tower is None or images is None or input_ids.shape[1] == 1:           # llava_arch.py:150-152
+        return input_ids, position_ids, attention_mask, past_key_values, None, labels
+    cfg = self.config
+    if isinstance(images, list) or images.ndim == 5:                               # tiles per image (anyres) or ragged lists
+        tiles = [x.unsqueeze(0) if x.ndim == 3 else x for x in images] if isinstance(images, list) else list(images)
+        feats = self.encode_images(torch.cat(tiles, 0))
+        feats = list(torch.split(feats, [t.shape[0] for t in tiles], 0))
+        merge = getattr(cfg, "mm_patch_merge_type", "flat")
+        if merge.startswith("spatial") and getattr(cfg, "image_aspect_ratio", "square") != "anyres" and any(f.shape[0] > 1 for f in feats):
+            raise NotImplementedError                                            # as the reference (llava_arch.py:184-185)
+        tower_cfg = getattr(vision_tower, "config", None)
+        size = getattr(vision_tower, "s2_image_size", None) or (tower_cfg["image_cfg"]["image_size"] if isinstance(tower_cfg, dict)
+                                                                else getattr(tower_cfg, "image_size", None))
+        newline = getattr(getattr(self, "model", None), "image_newline", None)
+        image_features = S.merge_patch_features(feats, image_sizes if image_sizes is not None else [None] * len(feats), merge,
+                                                getattr(cfg, "image_grid_pinpoints", None), size, newline)
+    else:
+        image_features = self.encode_images(images)
+    if getattr(cfg, "tune_mm_mlp_adapter", False) and getattr(cfg, "mm_use_im_start_end", False):
+        raise NotImplementedError                                                # llava_arch.py:214-215
+    out = S.multimodal_splice(input_ids, position_ids, attention_mask, labels, image_features, self.get_model().embed_tokens.weight,
+                              getattr(cfg, "tokenizer_padding_side", "right"), getattr(cfg, "tokenizer_model_max_length", None))
+    return out[0], out[1], out[2], past_key_values, out[4], out[5]

@@ -128,7 +128,7 @@ def merge_patch_features(features: Sequence[torch.Tensor], image_sizes, merge_ty
         raise ValueError("mm_patch_merge_type with 'unpad' needs the model's image_newline parameter")
     from .preprocess import _best_resolution
     out = []
-    for f, (ow, oh) in zip(features, image_sizes):
+    for f, size in zip(features, image_sizes):
         if f.shape[0] == 1:                              # a single tile: its tokens (+ one newline token)
             g = f[0]
             out.append(torch.cat([g, image_newline[None].to(g.device, g.dtype)], 0) if unpad else g)
@@ -138,6 +138,7 @@ def merge_patch_features(features: Sequence[torch.Tensor], image_sizes, merge_ty
         if isinstance(grid_pinpoints, str):
             import ast
             grid_pinpoints = ast.literal_eval(grid_pinpoints)
+        ow, oh = size
         base, tiles = f[0], f[1:]
         side, hid = int(round(base.shape[0] ** 0.5)), base.shape[-1]
         if side * side != base.shape[0]:
