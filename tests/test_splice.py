@@ -261,3 +261,45 @@ def test_prepare_inputs_replacement_routes_like_the_reference(case, monkeypatch)
             assert a.dtype == b.dtype and torch.equal(a, b)
         else:
             assert a == b
+
+
+@pytest.mark.gpu
+def test_prepare_inputs_replacement_on_the_gpu():
+    """the installed drop-in end to end on the device (list-of-tiles images, spatial_unpad merge, HIP splice) vs merge + oracle on CPU"""
+    from ml_fastvlm_amd import builder as B
+    from ml_fastvlm_amd.preprocess import _best_resolution
+    g = torch.Generator().manual_seed(4)
+    TS, side, H, V = 64, 4, 64, 80
+    grids = [[64, 128], [128, 64], [128, 128]]
+    sizes = [(150, 100), (60, 64)]
+    bw, bh = _best_resolution(*sizes[0], [tuple(p) for p in grids])
+    n0 = 1 + (bw // TS) * (bh // TS)
+    feats = [torch.randn(n0, side * side, H, generator=g).to(torch.bfloat16), torch.randn(1, side * side, H, generator=g).to(torch.bfloat16)]
+    newline = torch.randn(H, generator=g).to(torch.bfloat16)
+    W = torch.randn(V, H, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, V, (2, 12), generator=g)
+    ids[:, 3] = S.IMAGE_TOKEN_INDEX
+    mask = torch.ones_like(ids)
+    mask[0, 10:] = 0
+    labels = torch.randint(0, V, (2, 12), generator=g)
+
+    class Fake:
+        config = SimpleNamespace(tokenizer_padding_side="left", tokenizer_model_max_length=60, image_aspect_ratio="anyres",
+                                 mm_patch_merge_type="spatial_unpad", image_grid_pinpoints=str(grids))
+        model = SimpleNamespace(image_newline=newline.cuda())
+
+        def get_vision_tower(self):
+            return SimpleNamespace(num_patches_per_side=side, config={"image_cfg": {"image_size": TS}})
+
+        def get_model(self):
+            return SimpleNamespace(embed_tokens=SimpleNamespace(weight=W.cuda()))
+
+        def encode_images(self, x):
+            return torch.cat(feats, 0).cuda()
+
+    images = [torch.zeros(n0, 3, 2, 2).cuda(), torch.zeros(3, 2, 2).cuda()]
+    got = B.prepare_inputs_labels_for_multimodal(Fake(), ids.cuda(), None, mask.cuda(), "PKV", labels.cuda(), images, image_sizes=sizes)
+    merged = S.merge_patch_features(feats, sizes, "spatial_unpad", grids, TS, newline)
+    want = O.splice(ids, None, mask, labels, merged, W, "left", 60)
+    assert got[0] is None and got[1] is None and got[3] == "PKV"
+    assert torch.equal(got[4].cpu(), want[4]) and torch.equal(got[2].cpu(), want[2]) and torch.equal(got[5].cpu(), want[5])
