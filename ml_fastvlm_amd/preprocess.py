@@ -93,7 +93,6 @@ class _Plan:
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.hb, self.hc, self.vb, self.vc = dev(hb), dev(hc), dev(vb), dev(vc)
         self.lut = dev(_lut(1 / 255))
-        self.tmp = torch.empty((self.nrows, r, 3), dtype=torch.uint8, device=device)
 
 
 class _WindowPlan:
@@ -124,7 +123,6 @@ class _WindowPlan:
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
         self.hb, self.hc, self.vb, self.vc = dev(hb), dev(hc), dev(vb), dev(vc)
         self.lut = dev(_lut(1 / 255))
-        self.tmp = torch.empty((self.nrows, r, 3), dtype=torch.uint8, device=device)
 
 
 _plans = {}
@@ -132,9 +130,12 @@ _plans = {}
 
 def _run(plan, image, h, w, r, out):
     p = lambda t: C.c_void_p(t.data_ptr())
+    # scratch of the horizontal pass: per call from the stream-ordered caching allocator (a buffer cached in the plan would be
+    # shared by concurrent calls on different streams)
+    tmp = torch.empty((plan.nrows, r, 3), dtype=torch.uint8, device=image.device)
     _lib.check(_lib.load().fvhd_op_preprocess(_lib.stream_ptr(image.device), p(image), h, w, image.stride(0), plan.pad_top, plan.pad_left, 0,
                                               p(plan.hb), p(plan.hc), plan.hk, p(plan.vb), p(plan.vc), plan.vk, plan.row0, plan.nrows,
-                                              p(plan.tmp), p(plan.lut), r, p(out), _lib.dtype_code(out.dtype)), "fvhd_op_preprocess")
+                                              p(tmp), p(plan.lut), r, p(out), _lib.dtype_code(out.dtype)), "fvhd_op_preprocess")
 
 
 def _check_image(image):
