@@ -257,7 +257,7 @@ def main():
             return local_step()
         if args.tower_only or side == "after":
             return _all_gather(local_step())
-        return proj(_all_gather(tower(images)))
+        return fv.project(tower, proj, _all_gather(tower(images)))      # fvhd_project: the library's GEMMs, never torch.nn.Linear
 
     for _ in range(max(args.warmup, 1)):
         out = step()

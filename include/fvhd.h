@@ -55,7 +55,9 @@ void fvhd_destroy(fvhd_ctx* ctx);
 
 /* Size the workspace for `max_batch` images NOW.  Growing it (here, or implicitly when a larger batch reaches fvhd_encode*)
  * synchronises the device, frees and re-allocates the arena and drops the cached graphs - the only place where the library
- * synchronises.  It is refused while the caller's stream is being captured: reserve before capturing.  Every entry point
+ * synchronises.  Implicit growth inside fvhd_encode* / fvhd_project is refused while the caller's stream is being captured;
+ * fvhd_reserve itself takes no stream and must not be called while ANY stream of the device is capturing (it synchronises the
+ * device, which invalidates a capture): reserve before capturing.  Every entry point
  * that takes a context runs on the context's device and restores the caller's current device before returning. */
 int fvhd_reserve(fvhd_ctx* ctx, int max_batch);
 
@@ -143,7 +145,8 @@ int fvhd_profile_read(fvhd_ctx* ctx, int max_classes, const char** names, double
 
 /* ---- single ops (unit-test entry points; device pointers, packed layouts as documented) ---------- */
 /* depthwise conv, NHWC bf16: x [B,H,W,Cin] -> y [B,OH,OW,Cin*mult]; w fp32 [K*K][Cout]; bias fp32 [Cout] or NULL.
- * (K,stride,mult,gelu) in {(3,1,1,0),(3,2,1,1),(7,1,1,0),(7,2,2,1),(3,1,2,0)}  - mci.py:808-811, 575-586, 921, 992-995, 442-451, 1401-1411 */
+ * (K,stride,mult,gelu) in {(3,1,1,0),(3,2,1,1),(7,1,1,0),(7,2,2,1),(3,1,2,0)}  - mci.py:808-811, 575-586, 921, 992-995, 442-451, 1401-1411.
+ * Cin * mult must be a multiple of 32 (every FastViTHD width is: 96 ... 3072); any other combination is an error with a message. */
 int fvhd_op_dwconv(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias,
                    int B, int H, int W, int Cin, int K, int stride, int mult, int gelu);
 

@@ -63,17 +63,32 @@ def _is_mlp2x_gelu(p) -> bool:
             and p[0].out_features % 32 == 0 and p[0].in_features % 32 == 0)
 
 
+def library_projector(vision_tower, mm_projector) -> bool:
+    """True when `mm_projector` runs on the library's GEMM kernels: our tower, an `mlp2x_gelu` projector on the tower's HIP device,
+    and no gradient wanted through it (the HIP path is inference-only; a trainable projector under grad mode keeps autograd's
+    nn.Sequential, as the reference's training does)."""
+    return (isinstance(vision_tower, MobileCLIPVisionTower) and _is_mlp2x_gelu(mm_projector)
+            and mm_projector[0].weight.device == vision_tower.device and vision_tower.device.type == "cuda"
+            and not (torch.is_grad_enabled() and any(p.requires_grad for p in mm_projector.parameters())))
+
+
+def project(vision_tower, mm_projector, image_features):
+    """`mm_projector(image_features)` (llava_arch.py:143) for already-encoded tokens: `fvhd_project` whenever `library_projector`."""
+    if library_projector(vision_tower, mm_projector):
+        return vision_tower.project(image_features, mm_projector)
+    return mm_projector(image_features)
+
+
 def encode_images(vision_tower, mm_projector, images):
     """tower(images) -> mm_projector(features).  With our tower and an `mlp2x_gelu` projector on the
-    same HIP device this is ONE library call (tokens stay in bf16 workspace between the two)."""
-    if (isinstance(vision_tower, MobileCLIPVisionTower) and isinstance(images, torch.Tensor)
-            and _is_mlp2x_gelu(mm_projector) and mm_projector[0].weight.device == vision_tower.device
-            and not (torch.is_grad_enabled() and any(p.requires_grad for p in mm_projector.parameters()))):
+    same HIP device this is ONE library call (tokens stay in bf16 workspace between the two); a list of images is encoded as one
+    batch and every piece projected by the library too (`MobileCLIPVisionTower.project`)."""
+    if isinstance(images, torch.Tensor) and library_projector(vision_tower, mm_projector):
         return vision_tower.encode_images_with_projector(images, mm_projector)
     image_features = vision_tower(images)
     if isinstance(image_features, list):
-        return [mm_projector(f) for f in image_features]
-    return mm_projector(image_features)
+        return [project(vision_tower, mm_projector, f) for f in image_features]
+    return project(vision_tower, mm_projector, image_features)
 
 
 def install_into_llava(splice: bool = False) -> None:

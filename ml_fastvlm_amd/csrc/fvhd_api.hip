@@ -946,6 +946,13 @@ int fvhd_profile_read(fvhd_ctx* c, int max_classes, const char** names, double* 
 int fvhd_op_dwconv(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int Cin,
                    int K, int stride, int mult, int gelu)
 {
+    if (!x || !y || !w) return fail("fvhd_op_dwconv: NULL pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || mult <= 0 || (Cin * mult) % 32)
+        return fail("fvhd_op_dwconv: Cin * mult must be a positive multiple of 32 (got Cin=" + std::to_string(Cin) + " mult=" + std::to_string(mult) + ")");
+    const bool known = (K == 3 && stride == 1 && mult == 1 && !gelu) || (K == 3 && stride == 2 && mult == 1 && gelu) ||
+                       (K == 7 && stride == 1 && mult == 1 && !gelu) || (K == 7 && stride == 2 && mult == 2 && gelu) ||
+                       (K == 3 && stride == 1 && mult == 2 && !gelu);
+    if (!known) return fail("fvhd_op_dwconv: (K, stride, mult, gelu) must be one of (3,1,1,0) (3,2,1,1) (7,1,1,0) (7,2,2,1) (3,1,2,0)");
     int e = fvhd_launch_dwconv((hipStream_t)st, x, y, w, bias, B, H, W, Cin, K, stride, mult, gelu, 0);
     return e ? hip_fail("fvhd_op_dwconv", (hipError_t)e) : 0;
 }

@@ -92,3 +92,19 @@ def encode_images_sharded(tower_fn: Callable[[torch.Tensor], torch.Tensor], proj
     if side == "after":
         return all_gather_tokens(projector_fn(tokens), global_batch, group=group)
     return projector_fn(all_gather_tokens(tokens, global_batch, group=group))
+
+
+def encode_images_tower_sharded(vision_tower, mm_projector, images_local: torch.Tensor, global_batch: int, group=None,
+                                side: Optional[str] = None) -> torch.Tensor:
+    """`encode_images_sharded` for a tower + projector pair: both legs run in the library whenever `builder.library_projector` holds -
+    side "after": ONE fused `fvhd_encode_images` call per rank, then the gather; side "before" (H > 3072, FastVLM-7B): `fvhd_encode`,
+    the gather of the 3072-wide tokens, then `fvhd_project` on all `global_batch` images (never torch.nn.Linear)."""
+    from . import builder
+    hidden = mm_projector[0].out_features if isinstance(mm_projector, torch.nn.Sequential) else getattr(mm_projector, "out_features", TOWER_WIDTH)
+    side = side or gather_side(hidden)
+    if side == "after":
+        return all_gather_tokens(builder.encode_images(vision_tower, mm_projector, images_local), global_batch, group=group)
+    if side != "before":
+        raise ValueError(f"side must be 'before' or 'after', got {side!r}")
+    return builder.project(vision_tower, mm_projector, all_gather_tokens(vision_tower(images_local), global_batch, group=group))
+

@@ -14,6 +14,7 @@ no CPU path here.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import functools
 import math
@@ -90,7 +91,7 @@ class _Plan:
         self.row0 = int(vb[:, 0].min())
         self.nrows = int((vb[:, 0] + vb[:, 1]).max()) - self.row0
         self.hk, self.vk = hc.shape[1], vc.shape[1]
-        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        dev = lambda a: _upload(a, device)
         self.hb, self.hc, self.vb, self.vc = dev(hb), dev(hc), dev(vb), dev(vc)
         self.lut = dev(_lut(1 / 255))
 
@@ -120,22 +121,63 @@ class _WindowPlan:
         vb = vb.copy()
         vb[~oky, 0] = self.row0                               # empty rows: zero taps, any valid first row
         self.hk, self.vk = hc.shape[1], vc.shape[1]
-        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        dev = lambda a: _upload(a, device)
         self.hb, self.hc, self.vb, self.vc = dev(hb), dev(hc), dev(vb), dev(vc)
         self.lut = dev(_lut(1 / 255))
 
 
-_plans = {}
+def _upload(a: np.ndarray, device) -> torch.Tensor:
+    """tap tables -> device: through pinned memory without a host sync per table (5 tables per plan, 1 + patches plans per anyres image)"""
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
+class _PlanCache:
+    """LRU over the tap tables (a few KB of device memory each): arbitrary-size serving traffic evicts the oldest plan instead of
+    wiping the cache (an anyres image alone makes 1 + patches plans)."""
+
+    def __init__(self, capacity: int = 512):
+        self.capacity = capacity
+        self._d = collections.OrderedDict()
+
+    def get(self, key, make):
+        plan = self._d.get(key)
+        if plan is None:
+            plan = self._d[key] = make()
+            while len(self._d) > self.capacity:
+                self._d.popitem(last=False)      # its tensors carry record_stream marks (see _run): the allocator reuses them safely
+        else:
+            self._d.move_to_end(key)
+        return plan
+
+    def __len__(self):
+        return len(self._d)
+
+    def clear(self):
+        self._d.clear()
+
+
+_plans = _PlanCache()
 
 
 def _run(plan, image, h, w, r, out):
     p = lambda t: C.c_void_p(t.data_ptr())
-    # scratch of the horizontal pass: per call from the stream-ordered caching allocator (a buffer cached in the plan would be
-    # shared by concurrent calls on different streams)
-    tmp = torch.empty((plan.nrows, r, 3), dtype=torch.uint8, device=image.device)
-    _lib.check(_lib.load().fvhd_op_preprocess(_lib.stream_ptr(image.device), p(image), h, w, image.stride(0), plan.pad_top, plan.pad_left, 0,
-                                              p(plan.hb), p(plan.hc), plan.hk, p(plan.vb), p(plan.vc), plan.vk, plan.row0, plan.nrows,
-                                              p(tmp), p(plan.lut), r, p(out), _lib.dtype_code(out.dtype)), "fvhd_op_preprocess")
+    dev = image.device
+    # The op-level C entry point takes a stream, not a device: launch with the image's device current so that the stream handle
+    # (and the kernel) belong to the device of the pointers - a tower on cuda:1 while cuda:0 is current (device_map) otherwise
+    # launches on the wrong GPU.
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        # scratch of the horizontal pass: per call from the stream-ordered caching allocator (a buffer cached in the plan would be
+        # shared by concurrent calls on different streams)
+        tmp = torch.empty((plan.nrows, r, 3), dtype=torch.uint8, device=dev)
+        for t in (plan.hb, plan.hc, plan.vb, plan.vc, plan.lut):
+            t.record_stream(stream)              # plans are created on one stream and used on others; eviction must not recycle them early
+        _lib.check(_lib.load().fvhd_op_preprocess(C.c_void_p(stream.cuda_stream), p(image), h, w, image.stride(0), plan.pad_top, plan.pad_left, 0,
+                                                  p(plan.hb), p(plan.hc), plan.hk, p(plan.vb), p(plan.vc), plan.vk, plan.row0, plan.nrows,
+                                                  p(tmp), p(plan.lut), r, p(out), _lib.dtype_code(out.dtype)), "fvhd_op_preprocess")
 
 
 def _check_image(image):
@@ -178,11 +220,7 @@ def process_anyres_image(image: torch.Tensor, image_size: int, grid_pinpoints, d
     out = torch.empty((len(windows), 3, s, s), dtype=dtype, device=image.device)
     for n, (rh, rw, oy, ox, wy, wx) in enumerate(windows):
         key = ("win", h, w, rh, rw, oy, ox, wy, wx, s, image.device.index)
-        plan = _plans.get(key)
-        if plan is None:
-            if len(_plans) > 64:
-                _plans.clear()
-            plan = _plans[key] = _WindowPlan(h, w, rh, rw, oy, ox, wy, wx, s, image.device)
+        plan = _plans.get(key, lambda: _WindowPlan(h, w, rh, rw, oy, ox, wy, wx, s, image.device))
         if plan.empty:
             out[n].zero_()
         else:
@@ -197,11 +235,7 @@ def preprocess_image(image: torch.Tensor, image_size: int, pad: bool = True, dty
     image = _check_image(image)
     h, w, r = int(image.shape[0]), int(image.shape[1]), int(image_size)
     key = (h, w, r, bool(pad), image.device.index)
-    plan = _plans.get(key)
-    if plan is None:
-        if len(_plans) > 64:
-            _plans.clear()
-        plan = _plans[key] = _Plan(h, w, r, bool(pad), image.device)
+    plan = _plans.get(key, lambda: _Plan(h, w, r, bool(pad), image.device))
     if out is None:
         out = torch.empty((3, r, r), dtype=dtype, device=image.device)
     _run(plan, image, h, w, r, out)

@@ -43,7 +43,7 @@ def flatten_features(image_features: Union[torch.Tensor, Sequence[torch.Tensor]]
 
 def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], feat_lens: torch.Tensor,
                 max_length: Optional[int] = None):
-    """-> start [B, L] int32, seqlen [B] int32, feat_row0 [B, L] int64, keep [B, L] bool, max_len (int; the one host sync).
+    """-> start [B, L] int32, seqlen [B] int32, feat_row0 [B, L] int64, keep [B, L] bool, max_len (int; the ONE host sync).
     start[b, j] = output position of input token j inside sample b's spliced sequence (exclusive prefix sum of the token
     lengths: 0 for positions the attention mask drops, the image's row count for a -200 token, 1 otherwise)."""
     if input_ids.dim() != 2:
@@ -55,8 +55,6 @@ def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
     base = torch.cumsum(slots, 0) - slots
     rank = torch.cumsum(is_img.to(torch.int64), 1) - is_img.to(torch.int64)
     n_feat = feat_lens.shape[0]
-    if int(slots.sum()) > n_feat:
-        raise ValueError(f"the batch needs {int(slots.sum())} image-feature entries, {n_feat} given")
     img_idx = torch.clamp(base[:, None] + rank, max=n_feat - 1)
     feat_off = torch.cumsum(feat_lens, 0) - feat_lens
     tok_len = torch.where(is_img, feat_lens[img_idx], torch.ones_like(input_ids)) * keep
@@ -65,15 +63,94 @@ def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
     if max_length is not None:
         seqlen = torch.clamp(seqlen, max=int(max_length))      # llava_arch.py:292-296
     feat_row0 = torch.where(is_img, feat_off[img_idx], torch.full_like(input_ids, -1))
-    max_len = int(seqlen.max())
-    return start.to(torch.int32), seqlen.to(torch.int32), feat_row0.to(torch.int64), keep, max_len
+    need, max_len = torch.stack([slots.sum(), seqlen.max()]).tolist()      # one device-to-host transfer for both scalars
+    if need > n_feat:
+        raise ValueError(f"the batch needs {need} image-feature entries, {n_feat} given")
+    return start.to(torch.int32), seqlen.to(torch.int32), feat_row0.to(torch.int64), keep, int(max_len)
+
+
+def splice_sources(ids: torch.Tensor, start: torch.Tensor, seqlen: torch.Tensor, feat_row0: torch.Tensor, max_len: int, left_pad: bool):
+    """The source of every output row [B, max_len], as the kernel's binary search finds it (csrc/splice.hip) - in torch, for the
+    BACKWARD pass only: (table_row, feat_row), each -1 where the row does not come from that source (padding rows: both -1)."""
+    B, L = ids.shape
+    t = torch.arange(max_len, device=ids.device, dtype=torch.int64)[None, :]
+    ln = seqlen.to(torch.int64)[:, None]
+    u = t - ((max_len - ln) if left_pad else torch.zeros_like(ln))
+    valid = (u >= 0) & (u < ln)
+    uc = torch.clamp(u, min=0)
+    st = start.to(torch.int64)
+    j = torch.clamp(torch.searchsorted(st, uc.contiguous(), right=True) - 1, min=0, max=L - 1)    # last j with start[b, j] <= u
+    f0 = feat_row0.gather(1, j)
+    is_img = valid & (f0 >= 0)
+    feat_row = torch.where(is_img, f0 + (uc - st.gather(1, j)), torch.full_like(f0, -1))
+    table_row = torch.where(valid & (f0 < 0), ids.gather(1, j), torch.full_like(f0, -1))
+    return table_row, feat_row
+
+
+def splice_backward(grad_out: torch.Tensor, table_row: torch.Tensor, feat_row: torch.Tensor, vocab: int, n_feat_rows: int):
+    """d(inputs_embeds) -> (d embed_tokens.weight [vocab, H], d image features [n_feat_rows, H]): the transpose of the gather, i.e. a
+    scatter-add of the output-row gradients onto their source rows (a token id may occur many times; a feature row occurs at most once)."""
+    H = grad_out.shape[-1]
+    g = grad_out.reshape(-1, H)
+    tr, fr = table_row.reshape(-1), feat_row.reshape(-1)
+    gt = torch.zeros((vocab, H), dtype=grad_out.dtype, device=grad_out.device)
+    gf = torch.zeros((n_feat_rows, H), dtype=grad_out.dtype, device=grad_out.device)
+    mt = (tr >= 0) & (tr < vocab)
+    mf = (fr >= 0) & (fr < n_feat_rows)
+    gt.index_add_(0, tr[mt], g[mt])
+    gf.index_add_(0, fr[mf], g[mf])
+    return gt, gf
+
+
+def _launch(ids, start, seqlen, row0, lab_in, table, feats, max_len: int, left_pad: bool):
+    """ONE kernel: inputs_embeds + attention mask + position ids (+ labels).  Launched with the tensors' device current
+    (the op-level C entry points take a stream, not a device: the stream handle must belong to the device of the pointers)."""
+    dev = table.device
+    B, L = ids.shape
+    V, H = table.shape
+    out = torch.empty((B, max_len, H), device=dev, dtype=table.dtype)
+    mask_out = torch.empty((B, max_len), device=dev, dtype=torch.uint8)
+    pos_out = torch.empty((B, max_len), device=dev, dtype=torch.int64)
+    lab_out = None if lab_in is None else torch.empty((B, max_len), device=dev, dtype=torch.int64)
+    p = lambda t: C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().fvhd_op_splice(_lib.stream_ptr(dev), p(ids), p(start), p(seqlen), p(row0), p(lab_in), p(table), p(feats),
+                                              p(out), p(mask_out), p(pos_out), p(lab_out), B, L, H, max_len, V, feats.shape[0],
+                                              int(left_pad), _lib.dtype_code(table.dtype)), "fvhd_op_splice")
+    return out, mask_out, pos_out, lab_out
+
+
+class _SpliceFn(torch.autograd.Function):
+    """The splice kernel with a backward: training (`labels` given, a trainable `mm_projector` and / or `embed_tokens`,
+    llava/train/train.py) needs d(inputs_embeds) to reach the image features and the embedding table.  Forward = the same HIP
+    kernel as inference; backward = `splice_backward` (index_add_ on the device)."""
+
+    @staticmethod
+    def forward(ctx, table, feats, ids, start, seqlen, row0, lab_in, max_len, left_pad):
+        out, mask_out, pos_out, lab_out = _launch(ids, start, seqlen, row0, lab_in, table, feats, max_len, left_pad)
+        ctx.save_for_backward(ids, start, seqlen, row0)
+        ctx.meta = (max_len, left_pad, table.shape[0], feats.shape[0])
+        ctx.mark_non_differentiable(mask_out, pos_out)
+        if lab_out is not None:
+            ctx.mark_non_differentiable(lab_out)
+        return out, mask_out, pos_out, lab_out
+
+    @staticmethod
+    def backward(ctx, g_out, *_):
+        ids, start, seqlen, row0 = ctx.saved_tensors
+        max_len, left_pad, vocab, n_rows = ctx.meta
+        tr, fr = splice_sources(ids, start, seqlen, row0, max_len, left_pad)
+        gt, gf = splice_backward(g_out.contiguous(), tr, fr, vocab, n_rows)
+        return (gt if ctx.needs_input_grad[0] else None, gf if ctx.needs_input_grad[1] else None) + (None,) * 7
 
 
 def multimodal_splice(input_ids: torch.Tensor, position_ids: Optional[torch.Tensor], attention_mask: Optional[torch.Tensor],
                       labels: Optional[torch.Tensor], image_features, embed_weight: torch.Tensor,
                       padding_side: str = "right", max_length: Optional[int] = None):
     """Returns (None, position_ids, attention_mask, None, inputs_embeds, labels) exactly like the reference
-    (`llava_arch.py:332`; the fourth entry is past_key_values, passed through by the caller)."""
+    (`llava_arch.py:332`; the fourth entry is past_key_values, passed through by the caller).  Differentiable with respect to
+    `embed_weight` and the image features when gradients are enabled (scatter-add backward), so the drop-in also serves the
+    reference's training contract (`labels` given, trainable projector / embeddings)."""
     if embed_weight.device.type != "cuda":
         raise RuntimeError("multimodal_splice (MI355X): tensors must be on a HIP device - this path has no CPU implementation")
     dev = embed_weight.device
@@ -83,20 +160,24 @@ def multimodal_splice(input_ids: torch.Tensor, position_ids: Optional[torch.Tens
     am = None if attention_mask is None else attention_mask.to(dev)
     start, seqlen, row0, _, max_len = splice_plan(ids, am, lens.to(dev), max_length)
     B, L = ids.shape
-    V, H = embed_weight.shape
-    out = torch.empty((B, max_len, H), device=dev, dtype=embed_weight.dtype)
-    mask_out = torch.empty((B, max_len), device=dev, dtype=torch.uint8)
-    pos_out = torch.empty((B, max_len), device=dev, dtype=torch.int64)
+    H = embed_weight.shape[1]
     lab_in = None if labels is None else labels.to(device=dev, dtype=torch.int64).contiguous()
-    lab_out = None if labels is None else torch.empty((B, max_len), device=dev, dtype=torch.int64)
-    p = lambda t: C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
-    _lib.check(_lib.load().fvhd_op_splice(_lib.stream_ptr(dev), p(ids), p(start.contiguous()), p(seqlen.contiguous()), p(row0.contiguous()),
-                                          p(lab_in), p(embed_weight.contiguous()), p(feats), p(out), p(mask_out), p(pos_out), p(lab_out),
-                                          B, L, H, max_len, V, feats.shape[0], int(padding_side == "left"), _lib.dtype_code(embed_weight.dtype)),
-               "fvhd_op_splice")
+    if max_len == 0:          # every position masked out: the reference returns empty [B, 0, ...] tensors (llava_arch.py:297-322)
+        out = embed_weight.new_zeros((B, 0, H))
+        mask_out = torch.zeros((B, 0), device=dev, dtype=torch.uint8)
+        pos_out = torch.zeros((B, 0), device=dev, dtype=torch.int64)
+        lab_out = None if labels is None else torch.zeros((B, 0), device=dev, dtype=torch.int64)
+    else:
+        args = (embed_weight.contiguous(), feats, ids, start.contiguous(), seqlen.contiguous(), row0.contiguous(), lab_in, max_len,
+                padding_side == "left")
+        if torch.is_grad_enabled() and (embed_weight.requires_grad or feats.requires_grad):
+            out, mask_out, pos_out, lab_out = _SpliceFn.apply(*args)
+        else:
+            out, mask_out, pos_out, lab_out = _launch(args[2], args[3], args[4], args[5], lab_in, args[0], feats, max_len, args[8])
     new_mask = None if attention_mask is None else mask_out.to(attention_mask.dtype)      # llava_arch.py:325-328
     new_pos = None if position_ids is None else pos_out.to(position_ids.dtype)            # :330-331
-    return None, new_pos, new_mask, None, out, lab_out
+    new_lab = None if labels is None else lab_out.to(labels.dtype)                        # the reference builds them with labels.dtype (:299)
+    return None, new_pos, new_mask, None, out, new_lab
 
 
 def _unpad_window(cur_h: int, cur_w: int, orig_w: int, orig_h: int):

@@ -34,11 +34,20 @@ def _nhwc_bf16(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
 
 
-def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16):
+def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16, batch_invariant=None, replicate=1, expect_fused_ffn=None):
+    """batch_invariant: the tower option (None = default per-batch kernel selection, True = selection by image shape only, which at
+    B = 1 forces the big-batch kernel set: fused ConvFFN at C = 192 / 384, matrix-core dw7x7).  replicate = k: the GPU sees every
+    distinct image k times (batch * k rows, expanded on the device) so that the DEFAULT selection takes the kernels of a large batch
+    - the set bench.py times at B = 32 - while the CPU emulation only computes the distinct images; every copy must equal row-for-row."""
     tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{res}", SimpleNamespace(unfreeze_mm_vision_tower=False))
     tower.vision_tower.model.load_state_dict(sd, strict=True)
     tower = tower.to(DEV, param_dtype)             # as model/builder.py:173 does: the PARAMETERS are cast too
+    tower.batch_invariant = batch_invariant
     ctx = tower._context()
+    if replicate > 1:
+        ctx.reserve(batch * replicate)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
     info = ctx.steps()
     # the emulation must see the weights the tower holds: bf16-rounded values when the module was cast to bf16
     # (GEMM weights are rounded to bf16 by the library in either case; depthwise taps, biases, norms and layer
@@ -58,9 +67,16 @@ def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16):
                 assert x.shape == (batch, cin, hin, hin), (name, x.shape, cin, hin)
                 xin = _nhwc_bf16(x)
             last = i == len(fns) - 1
-            out = torch.empty((batch, hout * hout, cout) if last else (batch, hout, hout, cout), device=DEV, dtype=torch.bfloat16)
+            gb = batch * replicate
+            if replicate > 1:
+                xin = xin.repeat(replicate, 1, 1, 1)                # rows b, b + batch, b + 2 batch ... are copies of image b
+            out = torch.empty((gb, hout * hout, cout) if last else (gb, hout, hout, cout), device=DEV, dtype=torch.bfloat16)
             ctx.run_steps(i, i, xin, out)
             torch.cuda.synchronize()
+            if replicate > 1:
+                copies = out.view(replicate, batch, *out.shape[1:])
+                assert all(torch.equal(copies[0], copies[k]) for k in range(1, replicate)), f"{name}: copies of one image differ inside a batch"
+                out = copies[0]
             got = out.float().cpu() if last else out.float().cpu().permute(0, 3, 1, 2)
             want_r = E.rb(want)
             assert torch.isfinite(got).all(), name
@@ -72,6 +88,12 @@ def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16):
             if rel > worst[0]:
                 worst = (rel, name)
             x = want_r if not last else None                        # teacher forcing: next step sees the emulation's output
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    print("launches per class:", {k: v[1] for k, v in prof.items() if v[1]})
+    if expect_fused_ffn is not None:                                # the kernel set under test is the one the caller meant to test
+        assert prof["ffn_fused"][1] == expect_fused_ffn, (prof["ffn_fused"], expect_fused_ffn)
+        assert prof["gemm_fc1"][1] == prof["gemm_fc2"][1] == 44 - expect_fused_ffn
     for r in rows:
         print("step %2d %-16s %-28s rel-L2 %.3e  max-abs/absmax %.3e  out-of-bound %d" % r)
     bad = [r for r in rows if r[3] > STEP_REL or r[5] > 0]
@@ -79,8 +101,12 @@ def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16):
     return worst
 
 
-def test_steps_teacher_forced_r256(synth_sd):
-    worst = _run_teacher_forced(256, 2, synth_sd, seed=3)
+# batch_invariant = True pins the kernel choice to the LARGE-batch set (fused ConvFFN for C <= 384: 38 launches, matrix-core dw7x7 on
+# every map >= 24 px wide) - the set bench.py times; None = the per-batch choice, which at B = 1 / 2 is the small-batch set (VALU
+# dw7x7, two tiled GEMMs below 24576 rows).  Both sets meet the same per-step tolerance.
+@pytest.mark.parametrize("inv", [None, True])
+def test_steps_teacher_forced_r256(synth_sd, inv):
+    worst = _run_teacher_forced(256, 2, synth_sd, seed=3, batch_invariant=inv, expect_fused_ffn=38 if inv else 0)
     print("worst step:", worst)
 
 
@@ -88,13 +114,24 @@ def test_steps_teacher_forced_r256_fp32_parameters(synth_sd):
     _run_teacher_forced(256, 1, synth_sd, seed=6, param_dtype=torch.float32)
 
 
-def test_steps_teacher_forced_r320_ragged(synth_sd):
-    # 320 -> maps 80, 40, 20, 10, 5: every tile edge is ragged
-    _run_teacher_forced(320, 1, synth_sd, seed=4)
+@pytest.mark.parametrize("inv", [None, True])
+def test_steps_teacher_forced_r320_ragged(synth_sd, inv):
+    # 320 -> maps 80, 40, 20, 10, 5: every tile edge is ragged (matrix-core dw7x7: 80 = 64 + 16 px strips, masked columns)
+    _run_teacher_forced(320, 1, synth_sd, seed=4, batch_invariant=inv, expect_fused_ffn=38 if inv else 0)
 
 
-def test_steps_teacher_forced_r1024(synth_sd):
-    _run_teacher_forced(1024, 1, synth_sd, seed=5)
+@pytest.mark.parametrize("inv", [None, True])
+def test_steps_teacher_forced_r1024(synth_sd, inv):
+    # default selection at B = 1: only stage 0 (65536 rows) takes the fused ConvFFN
+    _run_teacher_forced(1024, 1, synth_sd, seed=5, batch_invariant=inv, expect_fused_ffn=38 if inv else 2)
+
+
+def test_steps_teacher_forced_r1024_bench_batch(synth_sd):
+    """The kernel set of the BENCHMARK configuration (BASELINE.json configs[1]: B = 32 @1024x1024, default kernel selection): fused
+    ConvFFN at C = 96 / 192 / 384, matrix-core dw7x7 with 32-row chunks, LDS-DMA dw3x3, the 256x128 streaming GEMM for qkv / fc1 /
+    fc2 / 1x1 (>= 512 tiles), every step teacher-forced against the bf16-storage emulation at the per-step tolerance.  2 distinct
+    images x 16 copies: the emulation costs two images, the GPU launches are the bench's."""
+    _run_teacher_forced(1024, 2, synth_sd, seed=7, replicate=16, expect_fused_ffn=38)
 
 
 def test_run_steps_chain_equals_encode(synth_sd):

@@ -170,3 +170,25 @@ def test_hip_anyres_equals_the_oracle_bit_for_bit(h, w):
     assert got.shape == want.shape and np.array_equal(got.cpu().numpy(), want)
     both = PP.process_images([torch.from_numpy(a).cuda()] * 2, 64, "anyres", grid_pinpoints=GRIDS)
     assert both.shape == (2,) + want.shape
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_on_a_non_current_device_and_plan_cache_lru():
+    """the op-level entry points carry no device guard, so the host launches with the image's device current (with one
+    GPU visible the check is that the caller's device is untouched); the plan cache evicts its oldest entry instead of being wiped."""
+    dev = torch.device("cuda", torch.cuda.device_count() - 1)
+    torch.cuda.set_device(0)
+    a = _img(90, 130, 5)
+    got = PP.preprocess_image(torch.from_numpy(a).to(dev), 64, pad=True)
+    assert torch.cuda.current_device() == 0 and got.device == dev
+    assert np.array_equal(got.cpu().numpy(), O.preprocess(a, 64, pad=True))
+    side = torch.cuda.Stream(device=dev)                      # a plan made on one stream, used on another
+    with torch.cuda.stream(side):
+        got2 = PP.preprocess_image(torch.from_numpy(a).to(dev), 64, pad=True)
+    side.synchronize()
+    assert torch.equal(got2, got)
+    cache = PP._PlanCache(capacity=3)
+    made = []
+    for k in (1, 2, 3, 1, 4, 1, 5):
+        cache.get(k, lambda k=k: made.append(k) or k)
+    assert made == [1, 2, 3, 4, 5] and len(cache) == 3 and list(cache._d) == [4, 1, 5]

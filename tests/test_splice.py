@@ -152,6 +152,83 @@ def test_hip_splice_prefill_shape_b8():
     assert got[4].shape == (8, 285, 896) and torch.equal(got[4].cpu(), want[4])
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_sources_and_backward_match_autograd_of_the_oracle_walk(seed):
+    """the splice must carry gradients to embed_tokens.weight and to the image features (training contract,
+    llava_arch.py:257-283 builds inputs_embeds with differentiable ops).  `splice_sources` (the kernel's row -> source map, in torch)
+    reproduces the forward bit for bit, and `splice_backward` equals autograd through the oracle's per-sample walk."""
+    rnd = random.Random(200 + seed)
+    side = rnd.choice(["right", "left"])
+    max_length = rnd.choice([None, 20, 33])
+    ids, mask, labels, feats, W = _case(seed, T=rnd.choice([(16,), (5, 9, 16)]), with_mask=seed % 3 != 0, empty_sample=seed == 5)
+    Wg = W.clone().requires_grad_(True)
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    want = O.splice(ids, None, mask, labels, fg, Wg, side, max_length)[4]
+    g = torch.randn(want.shape, generator=torch.Generator().manual_seed(seed))
+    want.backward(g)
+    flat, lens = S.flatten_features(feats)
+    start, seqlen, row0, _, max_len = S.splice_plan(ids, mask, lens, max_length)
+    tr, fr = S.splice_sources(ids, start, seqlen, row0, max_len, side == "left")
+    fwd = torch.zeros_like(want)
+    fwd[tr >= 0] = W[tr[tr >= 0]]
+    fwd[fr >= 0] = flat[fr[fr >= 0]]
+    assert torch.equal(fwd, want.detach())
+    gt, gf = S.splice_backward(g, tr, fr, W.shape[0], flat.shape[0])
+    assert torch.allclose(gt, Wg.grad, rtol=1e-6, atol=1e-6)
+    want_gf = torch.cat([f.grad if f.grad is not None else torch.zeros_like(f) for f in fg], 0)
+    assert torch.allclose(gf, want_gf, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fully_masked_batch_returns_empty_outputs_and_label_dtype():
+    """llava_arch.py:297-322 with every position masked out: [B, 0, H] embeddings, [B, 0] mask / positions / labels, no kernel launch;
+    labels keep the caller's dtype (the reference builds them with labels.dtype, :299)."""
+    ids, _, labels, feats, W = _case(2, B=2, L=6, H=8)
+    mask = torch.zeros_like(ids)
+    lab32 = labels.to(torch.int32)
+    out = S.multimodal_splice(ids.cuda(), torch.arange(6).cuda(), mask.cuda(), lab32.cuda(), [f.cuda() for f in feats], W.cuda())
+    want = O.splice(ids, torch.arange(6), mask, lab32, feats, W)
+    for a, b in ((out[4], want[4]), (out[2], want[2]), (out[1], want[1]), (out[5], want[5])):
+        assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    assert out[4].shape == (2, 0, 8) and out[5].dtype == torch.int32
+    mask[0, :3] = 1
+    out = S.multimodal_splice(ids.cuda(), None, mask.cuda(), lab32.cuda(), [f.cuda() for f in feats], W.cuda())
+    want = O.splice(ids, None, mask, lab32, feats, W)
+    assert out[5].dtype == torch.int32 and torch.equal(out[5].cpu(), want[5]) and torch.equal(out[4].cpu(), want[4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_hip_splice_is_differentiable(side):
+    """with gradients enabled and a trainable embedding table / projector output, the HIP splice carries
+    d(inputs_embeds) back to both (custom autograd.Function: kernel forward, scatter-add backward), equal to autograd through the
+    oracle's walk on CPU; under no_grad / frozen inputs the plain kernel path is taken and the output has no grad_fn."""
+    ids, mask, labels, feats, W = _case(11, B=4, L=30, H=64, V=300, T=(7, 16))
+    Wc = W.clone().requires_grad_(True)
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    want = O.splice(ids, None, mask, labels, fc, Wc, side, 50)[4]
+    g = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+    want.backward(g)
+    Wd = W.cuda().requires_grad_(True)
+    fd = [f.cuda().requires_grad_(True) for f in feats]
+    got = S.multimodal_splice(ids.cuda(), None, mask.cuda(), labels.cuda(), fd, Wd, side, 50)
+    assert got[4].requires_grad and torch.equal(got[4].detach().cpu(), want.detach())
+    assert not got[2].requires_grad and not got[5].requires_grad
+    got[4].backward(g.cuda())
+    assert torch.allclose(Wd.grad.cpu(), Wc.grad, rtol=1e-6, atol=1e-6)
+    for a, b in zip(fd, fc):
+        assert torch.allclose(a.grad.cpu() if a.grad is not None else torch.zeros_like(b), b.grad if b.grad is not None else torch.zeros_like(b),
+                              rtol=1e-6, atol=1e-6)
+    # projector-only training: frozen table, trainable features
+    Wf = W.cuda()
+    fd2 = [f.cuda().requires_grad_(True) for f in feats]
+    out = S.multimodal_splice(ids.cuda(), None, mask.cuda(), labels.cuda(), fd2, Wf, side, 50)[4]
+    out.sum().backward()
+    assert fd2[0].grad is not None
+    with torch.no_grad():
+        assert S.multimodal_splice(ids.cuda(), None, mask.cuda(), None, fd2, Wf, side, 50)[4].grad_fn is None
+
+
 def test_no_cpu_path():
     ids, mask, labels, feats, W = _case(0)
     with pytest.raises(RuntimeError, match="no CPU implementation"):
@@ -303,3 +380,16 @@ def test_prepare_inputs_replacement_on_the_gpu():
     want = O.splice(ids, None, mask, labels, merged, W, "left", 60)
     assert got[0] is None and got[1] is None and got[3] == "PKV"
     assert torch.equal(got[4].cpu(), want[4]) and torch.equal(got[2].cpu(), want[2]) and torch.equal(got[5].cpu(), want[5])
+
+
+@pytest.mark.gpu
+def test_hip_splice_on_a_non_current_device():
+    """fvhd_op_splice has no device guard; the host launches with the tensors' device current and leaves the caller's
+    current device alone (one GPU visible: the check is the untouched current device and a correct result)."""
+    dev = torch.device("cuda", torch.cuda.device_count() - 1)
+    torch.cuda.set_device(0)
+    ids, mask, labels, feats, W = _case(4, B=3, L=20, H=64, V=200)
+    want = O.splice(ids, None, mask, labels, feats, W, "right", None)
+    got = S.multimodal_splice(ids.to(dev), None, mask.to(dev), labels.to(dev), [f.to(dev) for f in feats], W.to(dev))
+    assert torch.cuda.current_device() == 0 and got[4].device == dev
+    assert torch.equal(got[4].cpu(), want[4]) and torch.equal(got[5].cpu(), want[5])
