@@ -134,7 +134,7 @@ int fvhd_set_attention_fp8(fvhd_ctx* ctx, int on);
 int fvhd_set_batch_invariant(fvhd_ctx* ctx, int on);
 
 /* hipGraph replay: on != 0 makes fvhd_encode / fvhd_encode_images capture the interior steps of the tower (everything between
- * the stem, which reads the caller's images, and the head, which writes the caller's buffer: ~170 launches on two streams)
+ * the stem, which reads the caller's images, and the head, which writes the caller's buffer: ~170 launches)
  * into one hipGraph per (batch, options) on the second call with that batch size and replay it from then on - the launch-bound
  * small-batch case (TTFT, B = 1..8).  The reference's analogue is none (eager PyTorch, mobileclip_encoder.py:70-88).
  * A caller that is itself stream-capturing gets plain launches.  Also FVHD_GRAPH=1 at fvhd_create.  Default off. */

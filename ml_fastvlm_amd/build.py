@@ -46,12 +46,15 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, ablate: bool = False, tag: str = "", defs=()) -> str:
     """ablate=True (or FVHD_FFN_ABLATE=1 on the command line): the experiment library `libfvhd_ablate.so` with the fused-FFN
     ablation variants and the kernel-selection knobs (fvhd_debug_set_*, -DFVHD_DEBUG_KNOBS) compiled in; tools/bench_ops.py picks
     it with FVHD_LIB for A/B runs.  Never what the package loads by default: the shipped library has no such switches."""
-    build_dir = BUILD + ("_ablate" if ablate else "")
-    lib = LIB.replace("libfvhd.so", "libfvhd_ablate.so") if ablate else LIB
+    # tag / defs (experiments only: FVHD_VARIANT_TAG=g5 FVHD_EXTRA_DEFS="-DFVHD_GELU_DEG=5"): a separately named library
+    # `libfvhd_<tag>.so` built with extra preprocessor definitions, for same-box A/B runs through FVHD_LIB
+    suffix = ("_ablate" if ablate else "") + (f"_{tag}" if tag else "")
+    build_dir = BUILD + suffix
+    lib = LIB.replace("libfvhd.so", f"libfvhd{suffix}.so")
     os.makedirs(build_dir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -64,7 +67,7 @@ def build_library(force: bool = False, verbose: bool = False, ablate: bool = Fal
         o = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            extra = EXTRA_FLAGS.get(src, []) + (["-DFVHD_DEBUG_KNOBS"] if ablate else []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
+            extra = EXTRA_FLAGS.get(src, []) + list(defs) + (["-DFVHD_DEBUG_KNOBS"] if ablate else []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
             jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
@@ -85,4 +88,5 @@ def build_library(force: bool = False, verbose: bool = False, ablate: bool = Fal
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True, ablate=os.environ.get("FVHD_FFN_ABLATE") == "1"))
+    print(build_library(force="--force" in sys.argv, verbose=True, ablate=os.environ.get("FVHD_FFN_ABLATE") == "1",
+                        tag=os.environ.get("FVHD_VARIANT_TAG", ""), defs=os.environ.get("FVHD_EXTRA_DEFS", "").split()))

@@ -144,23 +144,17 @@ struct fvhd_ctx {
     int ws_batch = 0, ws_hidden = 0;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
     bool use_fused_stem = true;  // FVHD_FUSED_STEM=0: stem[0] and stem[1] as two launches through a [B,R/2,R/2,96] HBM tensor
-    // The batch is encoded as two independent halves on two HIP streams (FVHD_DUAL=0 disables): images are independent
-    // through the whole tower, and the MFMA-heavy ConvFFN kernels of one half co-run on the CUs with the VALU-bound
-    // depthwise kernels / HBM-bound prologues of the other.  aux joins back into the caller's stream before returning.
-    int dual = 1;
     int batch_invariant = 0;     // fvhd_set_batch_invariant: kernel choice by image shape only (bit-identical rows in any batch)
     int attn_fp8 = 0;            // fvhd_set_attention_fp8 / FVHD_ATTN_FP8=1: e4m3 MFMA operands in MHSA (BASELINE.json configs[4])
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // hipGraph replay of the interior steps (fvhd_set_graph / FVHD_GRAPH=1): ~170 launches become one hipGraphLaunch.
     // The stem (reads the caller's images) and the head (writes the caller's buffer) stay outside the graph, so a cached
     // graph only holds library-owned pointers (workspace, packed weights) and is valid for any caller buffers.
     struct GraphEntry {
-        int B, attn_fp8, dual, fused;   // fused: bit 0 fused ConvFFN, bit 1 batch-invariant dispatch
+        int B, attn_fp8, fused;    // fused: bit 0 fused ConvFFN, bit 1 batch-invariant dispatch
         char* ws;
         hipGraphExec_t exec;       // nullptr until the second call with this key (the first runs eagerly), or when capture failed
         bool failed;
-        char *X0, *T0, *X1, *T1;   // activation ping-pong state after the interior steps
+        char *X, *T;               // activation ping-pong state after the interior steps
     };
     int graph = 0;
     std::vector<GraphEntry> graphs;
@@ -488,44 +482,17 @@ int prepare(fvhd_ctx* c, int B, hipStream_t st)          // the caller holds a D
     return ensure_ws(c, B, st, true);
 }
 
-// the part of workspace `w` (carved for `total` images) that belongs to the images [b0, total)
-Ws sub_ws(const fvhd_ctx* c, const Ws& w, int b0)
-{
-    const size_t unit1 = (size_t)(c->R / 4) * (c->R / 4) * 96 * 2;     // per-image bytes of X / T / A (H: 4x)
-    Ws h = w;
-    h.X += unit1 * b0; h.T += unit1 * b0; h.A += unit1 * b0; h.H += 4 * unit1 * b0;
-    h.pooled += (size_t)b0 * (kOutDim + kSeRd);
-    h.scale += (size_t)b0 * kOutDim;
-    return h;
-}
-
 size_t dtype_size(int dt) { return dt == FVHD_F32 ? 4 : 2; }
 
-// Steps [first, last] for the whole batch on `st`, or - dualmode - as two independent halves on `st` and c->aux (forked
-// from and joined back into `st`).  (X0, T0) / (X1, T1): activation ping-pong buffers of the halves, updated in place.
-int run_range(fvhd_ctx* c, hipStream_t st, int first, int last, bool dualmode, const Ws& w, const Ws& w1, int B0, int B1,
-              char*& X0, char*& T0, char*& X1, char*& T1, const void* img0, const void* img1, int img_dtype,
-              void* out0, void* out1, int out_dtype)
+// Steps [first, last] for the whole batch on `st` (X, T: the activation ping-pong buffers, updated in place).  The whole batch
+// runs on the caller's stream: round 1-2 split it into two half-batches on two streams, which measured +0.4 % at B = 32 (the
+// hardware does not co-schedule the MFMA-bound and the memory-bound kernels of the halves) and doubled the launch / graph logic.
+int run_range(fvhd_ctx* c, hipStream_t st, int first, int last, const Ws& w, int B, char*& X, char*& T, const void* img,
+              int img_dtype, void* out, int out_dtype)
 {
     int e;
-    if (!dualmode) {
-        for (int i = first; i <= last; ++i)
-            if ((e = run_step(c, st, c->m.steps[i], w, X0, T0, B0, img0, img_dtype, out0, out_dtype))) return e;
-        return 0;
-    }
-    hipError_t he = hipEventRecord(c->ev_fork, st);
-    if (he == hipSuccess) he = hipStreamWaitEvent(c->aux, c->ev_fork, 0);
-    if (he != hipSuccess) return hip_fail("fork", he);
-    const int n = last - first + 1;
-    const int skew = c->dual >= 2 ? c->dual - 1 : 0;     // FVHD_DUAL=k+1: the second half is issued k steps behind the first
-    for (int i = 0; i < n + skew; ++i) {
-        if (i < n && (e = run_step(c, st, c->m.steps[first + i], w, X0, T0, B0, img0, img_dtype, out0, out_dtype))) return e;
-        const int j = i - skew;
-        if (j >= 0 && (e = run_step(c, c->aux, c->m.steps[first + j], w1, X1, T1, B1, img1, img_dtype, out1, out_dtype))) return e;
-    }
-    he = hipEventRecord(c->ev_join, c->aux);
-    if (he == hipSuccess) he = hipStreamWaitEvent(st, c->ev_join, 0);
-    if (he != hipSuccess) return hip_fail("join", he);
+    for (int i = first; i <= last; ++i)
+        if ((e = run_step(c, st, c->m.steps[i], w, X, T, B, img, img_dtype, out, out_dtype))) return e;
     return 0;
 }
 
@@ -536,48 +503,33 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
     if (e) return e;
     const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
     const int n = (int)c->m.steps.size();
-    // profiling brackets single launches with events: keep them on one stream, un-overlapped
-    // two half-batches on two streams pay from ~12 images on (B = 16: 13.40 vs 13.78 ms; B = 32: +0.4 %); below that the halves
-    // no longer fill the chip and fall under the small-batch kernel thresholds (B = 8: 8.25 vs 7.75 ms single-stream)
-    const bool dualmode = c->dual && B >= 12 && !c->prof;
-    if (dualmode && !c->aux) {
-        hipError_t he = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-        if (he != hipSuccess) return hip_fail("aux stream/event creation", he);
-    }
-    const int B0 = dualmode ? B / 2 : B, B1 = B - B0;
-    const size_t Tn = (size_t)(c->R / 64) * (c->R / 64);
-    const Ws w1 = sub_ws(c, w, B0);
-    const void* img1 = (const char*)images + (size_t)B0 * 3 * c->R * c->R * dtype_size(img_dtype);
-    void* out1 = (char*)out + (size_t)B0 * Tn * kOutDim * dtype_size(out_dtype);
-    char *X0 = w.X, *T0 = w.T, *X1 = w1.X, *T1 = w1.T;
+    char *X = w.X, *T = w.T;
 
     bool use_graph = c->graph && !c->prof && n >= 3;
     if (use_graph) {                       // a caller that is itself capturing gets plain launches (they land in its graph)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_graph = false;
     }
-    if (!use_graph)
-        return run_range(c, st, 0, n - 1, dualmode, w, w1, B0, B1, X0, T0, X1, T1, images, img1, img_dtype, out, out1, out_dtype);
+    if (!use_graph) return run_range(c, st, 0, n - 1, w, B, X, T, images, img_dtype, out, out_dtype);
 
-    // ---- stem (whole batch: its output layout is the halves' layout) | graph of the interior steps | head per half ----
-    if ((e = run_step(c, st, c->m.steps[0], w, X0, T0, B, images, img_dtype, nullptr, 0))) return e;
+    // ---- stem | graph of the interior steps | head ----
+    if ((e = run_step(c, st, c->m.steps[0], w, X, T, B, images, img_dtype, nullptr, 0))) return e;
+    const int fkey = (int)c->use_fused_ffn | (c->batch_invariant << 1);
     fvhd_ctx::GraphEntry* g = nullptr;
     for (auto& q : c->graphs)
-        if (q.B == B && q.attn_fp8 == c->attn_fp8 && q.dual == c->dual && q.fused == ((int)c->use_fused_ffn | (c->batch_invariant << 1)) && q.ws == c->ws) g = &q;
+        if (q.B == B && q.attn_fp8 == c->attn_fp8 && q.fused == fkey && q.ws == c->ws) g = &q;
     if (!g) {                              // first call with this key: eager (one-time kernel attributes are set on this pass)
-        if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
-        c->graphs.push_back({B, c->attn_fp8, c->dual, (int)c->use_fused_ffn | (c->batch_invariant << 1), c->ws, nullptr, false, X0, T0, X1, T1});
+        if ((e = run_range(c, st, 1, n - 2, w, B, X, T, nullptr, 0, nullptr, 0))) return e;
+        c->graphs.push_back({B, c->attn_fp8, fkey, c->ws, nullptr, false, X, T});
     } else if (g->failed) {
-        if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
+        if ((e = run_range(c, st, 1, n - 2, w, B, X, T, nullptr, 0, nullptr, 0))) return e;
     } else {
         if (!g->exec) {                    // second call: capture the same launch sequence instead of executing it
             hipGraph_t graph = nullptr;
             hipError_t he = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (he == hipSuccess) {
-                char *x0 = X0, *t0 = T0, *x1 = X1, *t1 = T1;
-                e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, x0, t0, x1, t1, nullptr, nullptr, 0, nullptr, nullptr, 0);
+                char *x = X, *t = T;
+                e = run_range(c, st, 1, n - 2, w, B, x, t, nullptr, 0, nullptr, 0);
                 he = hipStreamEndCapture(st, &graph);
                 if (e == 0 && he == hipSuccess && graph) he = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
                 else if (he == hipSuccess) he = hipErrorUnknown;
@@ -587,18 +539,16 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
                 (void)hipGetLastError();
                 g->exec = nullptr;
                 g->failed = true;
-                if ((e = run_range(c, st, 1, n - 2, dualmode, w, w1, B0, B1, X0, T0, X1, T1, nullptr, nullptr, 0, nullptr, nullptr, 0))) return e;
+                if ((e = run_range(c, st, 1, n - 2, w, B, X, T, nullptr, 0, nullptr, 0))) return e;
             }
         }
         if (g->exec) {
             hipError_t he = hipGraphLaunch(g->exec, st);
             if (he != hipSuccess) return hip_fail("hipGraphLaunch", he);
-            X0 = g->X0; T0 = g->T0; X1 = g->X1; T1 = g->T1;
+            X = g->X; T = g->T;
         }
     }
-    if ((e = run_step(c, st, c->m.steps[n - 1], w, X0, T0, B0, nullptr, 0, out, out_dtype))) return e;
-    if (dualmode && (e = run_step(c, st, c->m.steps[n - 1], w1, X1, T1, B1, nullptr, 0, out1, out_dtype))) return e;
-    return 0;
+    return run_step(c, st, c->m.steps[n - 1], w, X, T, B, nullptr, 0, out, out_dtype);
 }
 
 int project_impl(fvhd_ctx* c, const void* tokens, int in_dtype, int rows, void* out, int out_dtype, hipStream_t st,
@@ -642,7 +592,6 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_FUSED_STEM")) c->use_fused_stem = atoi(ev) != 0;
-    if (const char* ev = getenv("FVHD_DUAL")) c->dual = atoi(ev);
     if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_GRAPH")) c->graph = atoi(ev) != 0;
     *out = c;
@@ -657,9 +606,6 @@ void fvhd_destroy(fvhd_ctx* c)
     for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& ev : c->ev_pool) (void)hipEventDestroy(ev);
     clear_graphs(c);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->pdev) (void)hipFree(c->pdev);
     if (c->ws) (void)hipFree(c->ws);

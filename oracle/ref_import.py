@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY - imports the *reference's own* FastViTHD code, unmodified.
 
 Used (a) by `oracle/make_golden.py` to generate the golden fixtures committed under
-`tests/golden/`, and (b) by the `-m "not gpu"` pinning tests when `/root/reference`
-is present.  `/root/reference` does not exist on the GPU box; nothing that runs there
-imports this module.
+`tests/golden/`, (b) by the `-m "not gpu"` pinning tests when `/root/reference`
+is present, and (c) on the GPU box - where `/root/reference` does not exist - by
+`tests/test_gpu_reference.py` and bench.py's `cpu_baseline`, through the archive that
+`oracle/stage_reference.py` stages under the git-ignored `oracle/_ref/` at build time.
 
 The reference's hot path imports `timm` (registry + DropPath + two constants,
 `mci.py:15-17`, `mobileclip/__init__.py:10`), which is not installed in this image.
@@ -20,13 +21,27 @@ from types import SimpleNamespace
 
 import torch.nn as nn
 
-REFERENCE_ROOT = os.environ.get("FVHD_REFERENCE_ROOT", "/root/reference")
+_MCI = "llava/model/multimodal_encoder/mobileclip/mci.py"
+
+
+def _resolve_root() -> str:
+    """FVHD_REFERENCE_ROOT, else the mounted checkout (build container), else the archive `oracle/stage_reference.py` staged under
+    `oracle/_ref/` (GPU box), extracted into a scratch directory outside the repository."""
+    env = os.environ.get("FVHD_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isfile(os.path.join("/root/reference", _MCI)):
+        return "/root/reference"
+    from . import stage_reference
+    return stage_reference.unpack() or "/root/reference"
+
+
+REFERENCE_ROOT = _resolve_root()
 _REGISTRY = {}
 
 
 def reference_available() -> bool:
-    return os.path.isfile(os.path.join(
-        REFERENCE_ROOT, "llava/model/multimodal_encoder/mobileclip/mci.py"))
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, _MCI))
 
 
 def install_timm_stub() -> None:

@@ -1,0 +1,141 @@
+"""The REFERENCE ITSELF on the GPU box, beside our tower (VERDICT r2 "missing" #3 / next-round item 6).
+
+`/root/reference` does not exist on the GPU box; `__graft_entry__.build()` stages the reference's own `llava` package, unmodified,
+as `oracle/_ref/reference_llava.zip` (git-ignored, shipped with the tree like libfvhd.so; `oracle/stage_reference.py`), and
+`oracle/ref_import.py` imports it from a scratch directory.  Two checks:
+
+ (a) the reference's `MobileCLIPVisionTower` executed by PyTorch-ROCm in fp32 (1024x1024, B = 4) against our tower on the same
+     weights and images - the first direct GPU-vs-reference comparison.  STATED TOLERANCE (mild weight set):
+     rel-L2 <= 1e-2, cosine >= 0.9999, max-abs <= 3e-2 * absmax.
+ (b) the reference's `LlavaQwen2ForCausalLM.generate(images=...)` (`predict.py:55-65` -> `llava_qwen.py:118-134` ->
+     `llava_arch.py:146-332`), once un-patched (reference tower + reference splice walk, fp32 on the GPU) and once after
+     `install_into_llava(splice=True)` (our tower through the C ABI + the HIP splice kernel) with the SAME state dict loaded
+     strictly: first-token logits agree to rel-L2 <= 3e-2 (bf16 tower arithmetic under an fp32 LLM) and the greedy token is
+     the same wherever the reference's own top-2 margin exceeds that error.
+MIOpen is switched off for the reference runs (`torch.backends.cudnn.flags(enabled=False)`: ATen's native HIP convolutions) so a
+fresh box does not spend minutes compiling MIOpen kernels; the arithmetic is fp32 either way.
+"""
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import ml_fastvlm_amd as fv
+from ml_fastvlm_amd import synth
+from oracle import ref_import
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_import.reference_available(),
+                                 reason="reference not staged (run __graft_entry__.build() where /root/reference is mounted)")]
+DEV = "cuda:0"
+ARGS = SimpleNamespace(unfreeze_mm_vision_tower=False)
+
+
+def _metrics(got, want):
+    got, want = got.double().cpu().flatten(), want.double().cpu().flatten()
+    rel = ((got - want).norm() / want.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=0).item()
+    mx = ((got - want).abs().max() / want.abs().max()).item()
+    return rel, cos, mx
+
+
+@pytest.mark.parametrize("res,batch", [(256, 2), (1024, 4)])
+def test_our_tower_vs_the_reference_tower_on_pytorch_rocm(res, batch):
+    sd = synth.synthetic_state_dict(1234, "mild")
+    ref = ref_import.build_reference_tower(res)
+    ref.vision_tower.model.load_state_dict(sd, strict=True)
+    ref = ref.to(DEV, torch.float32)
+    x = synth.synthetic_images(batch, res, seed=41).to(DEV)
+    with torch.backends.cudnn.flags(enabled=False), torch.no_grad():
+        want = ref(x)                                            # mobileclip_encoder.py:70-88 on PyTorch-ROCm, fp32
+    ours = fv.MobileCLIPVisionTower(f"mobileclip_l_{res}", ARGS)
+    ours.vision_tower.model.load_state_dict(sd, strict=True)
+    ours = ours.to(DEV, torch.bfloat16)
+    got = ours(x)                                                # fp32 images in -> fp32 tokens out, bf16 arithmetic inside
+    assert got.shape == want.shape == (batch, (res // 64) ** 2, 3072) and got.dtype == want.dtype == torch.float32
+    rel, cos, mx = _metrics(got, want)
+    print(f"ours vs reference-on-GPU (fp32) r{res} B={batch}: rel-L2 {rel:.3e} cos {cos:.6f} max-abs/absmax {mx:.3e}")
+    assert rel <= 1e-2 and cos >= 0.9999 and mx <= 3e-2, (rel, cos, mx)
+    # the reference's own properties our tower mirrors
+    assert ours.hidden_size == ref.hidden_size and ours.num_patches == ref.num_patches
+    assert set(ours.state_dict()) == set(ref.state_dict())
+
+
+def _llava_cfg(hidden=128):
+    from transformers import Qwen2Config
+    from llava.model.language_model.llava_qwen import LlavaConfig
+    cfg = LlavaConfig(**Qwen2Config(vocab_size=1024, hidden_size=hidden, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                    num_key_value_heads=2, max_position_embeddings=2048).to_dict())
+    cfg.mm_vision_tower, cfg.mm_projector_type, cfg.mm_hidden_size = "mobileclip_l_256", "mlp2x_gelu", 3072
+    cfg.unfreeze_mm_vision_tower = True          # llava_arch.py:35 builds with delay_load=True; this forces the load
+    cfg.tokenizer_padding_side, cfg.tokenizer_model_max_length = "right", 2048
+    return cfg
+
+
+def test_reference_generate_with_our_tower_underneath():
+    ref_import.install_timm_stub()
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    import llava.model.llava_arch as arch
+    import llava.model.multimodal_encoder.builder as enc_builder
+    from llava.model.language_model.llava_qwen import LlavaQwen2ForCausalLM
+    saved = (enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images,
+             arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal)
+    hidden = 128
+    tower_sd = synth.synthetic_state_dict(1234, "mild")
+    proj_sd = synth.synthetic_projector_state_dict(hidden, 1234)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 1024, (3, 14), generator=g)
+    ids[:, 5] = -200                                             # IMAGE_TOKEN_INDEX (llava/constants.py:8)
+    mask = torch.ones_like(ids)
+    mask[1, 11:] = 0                                             # a right-padded sample
+    images = synth.synthetic_images(3, 256, seed=17)
+
+    def run(model):
+        model = model.to(DEV).eval()
+        with torch.inference_mode(), torch.backends.cudnn.flags(enabled=False):
+            out = model.generate(ids.to(DEV), images=images.to(DEV), image_sizes=[(256, 256)] * 3, attention_mask=mask.to(DEV),
+                                 do_sample=False, max_new_tokens=2, use_cache=True, output_scores=True, return_dict_in_generate=True,
+                                 pad_token_id=0)
+        return out.sequences.cpu(), out.scores[0].float().cpu()
+
+    try:
+        torch.manual_seed(0)
+        ref_model = LlavaQwen2ForCausalLM(_llava_cfg(hidden))                       # UN-patched: the reference's own tower
+        assert type(ref_model.get_vision_tower()).__module__.startswith("llava.")
+        ref_model.get_vision_tower().vision_tower.model.load_state_dict(tower_sd, strict=True)
+        ref_model.get_model().mm_projector.load_state_dict(proj_sd, strict=True)
+        state = {k: v.clone() for k, v in ref_model.state_dict().items()}
+        seq_ref, logits_ref = run(ref_model)
+        del ref_model
+
+        fv.install_into_llava(splice=True)                                           # the whole reference-side patch
+        ours_model = LlavaQwen2ForCausalLM(_llava_cfg(hidden))
+        tower = ours_model.get_vision_tower()
+        assert isinstance(tower, fv.MobileCLIPVisionTower)
+        missing, unexpected = ours_model.load_state_dict(state, strict=True)         # the reference model's checkpoint, key for key
+        assert not missing and not unexpected
+        ours_model.get_model().mm_projector.requires_grad_(False)
+        ctx_probe = {}
+        real = tower.encode_images_with_projector
+
+        def spy(images_, projector):
+            ctx_probe["n"] = ctx_probe.get("n", 0) + 1
+            return real(images_, projector)
+        tower.encode_images_with_projector = spy
+        seq, logits = run(ours_model)
+        assert ctx_probe.get("n", 0) == 1, "generate() must reach the fused library call exactly once (prefill)"
+    finally:
+        (enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images,
+         arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal) = saved
+    rel, cos, mx = _metrics(logits, logits_ref)
+    print(f"first-token logits, patched vs un-patched reference model: rel-L2 {rel:.3e} cos {cos:.6f} max-abs/absmax {mx:.3e}")
+    assert logits.shape == logits_ref.shape == (3, 1024)
+    assert rel <= 3e-2 and cos >= 0.999, (rel, cos, mx)
+    top2 = logits_ref.topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    err = (logits - logits_ref).abs().max(dim=-1).values
+    for b in range(3):
+        if margin[b] > 2 * err[b]:
+            assert seq[b, 0] == seq_ref[b, 0], f"sample {b}: greedy first token differs although the reference's margin exceeds the error"

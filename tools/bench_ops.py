@@ -48,8 +48,7 @@ def timeit(fn, iters=20, warm=10):
 
 
 def bench_ffn(B=32):
-    """fused ConvFFN at the B = 32 stage shapes.  FVHD_FFN_PERSIST=1 selects the persistent kernels (read once per process: run
-    this twice for an A/B)."""
+    """fused ConvFFN at the B = 32 stage shapes"""
     for Cc, H in ((96, 256), (192, 128), (384, 64)):
         M, HID = B * H * H, 4 * Cc
         g = torch.Generator().manual_seed(0)
@@ -67,47 +66,7 @@ def bench_ffn(B=32):
         ls = torch.full((Cc,), 0.01, device=DEV)
         t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
         fl, by = 16.0 * M * Cc * Cc, 6.0 * M * Cc
-        print(f"ffn_fused C={Cc:4d} M={M:8d} persist={os.environ.get('FVHD_FFN_PERSIST', '0')}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.1f} GB/s (algorithmic)")
-
-
-def ffn_stamps(Cc=192):
-    """ablation library only (FVHD_LIB=libfvhd_ablate.so, FVHD_FFN_VARIANT=128|131|143): s_memtime stamps of workgroup 0"""
-    import numpy as np
-    H = {96: 256, 192: 128}[Cc]
-    M, HID = 32 * H * H, 4 * Cc
-    g = torch.Generator().manual_seed(0)
-    A = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
-    X = torch.randn(M, Cc, generator=g).to(DEV, torch.bfloat16)
-    W1 = (torch.randn(HID, Cc, generator=g) * Cc ** -0.5).to(torch.bfloat16).float().contiguous()
-    W2 = (torch.randn(Cc, HID, generator=g) * HID ** -0.5).to(torch.bfloat16).float().contiguous()
-    nch, che = HID // 32, 32 * Cc
-    i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
-    i2 = torch.empty(nch * che, dtype=torch.bfloat16)
-    _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
-    i1, i2 = i1.to(DEV), i2.to(DEV)
-    b1 = torch.randn(HID, generator=g).to(DEV) * 0.1
-    b2 = torch.randn(Cc, generator=g).to(DEV) * 0.1
-    ls = torch.full((Cc,), 0.01, device=DEV)
-    for _ in range(3):
-        _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc))
-    torch.cuda.synchronize()
-    raw = _knobs()
-    buf = (C.c_uint * (8 * 40 * 4))()
-    assert raw.fvhd_debug_ffn_stamps(buf) == 0
-    st = np.array(buf, dtype=np.int64).reshape(8, 40, 4)
-    t0 = st[:, 0, 0].min()
-    print(f"C={Cc} variant {os.environ.get('FVHD_FFN_VARIANT')}: per wave, iteration pairs 4..35: mean cycles  wait+barrier | even body | hooks | odd half (to next pair)")
-    for w in range(8):
-        s = st[w, 4:36]
-        nxt = st[w, 5:37, 0]
-        d = lambda a, b: float(((b - a) & 0xffffffff).mean())
-        print(f"  wave {w}: {d(s[:, 0], s[:, 1]):8.0f} | {d(s[:, 1], s[:, 2]):8.0f} | {d(s[:, 2], s[:, 3]):8.0f} | {d(s[:, 3], nxt):8.0f}   pair total {d(s[:, 0], nxt):8.0f}")
-    w = 0
-    print("  wave 0 pairs 8..20 (wait, body, hooks, odd):", [[int((st[w, i, 1] - st[w, i, 0]) & 0xffffffff), int((st[w, i, 2] - st[w, i, 1]) & 0xffffffff),
-                                                             int((st[w, i, 3] - st[w, i, 2]) & 0xffffffff), int((st[w, i + 1, 0] - st[w, i, 3]) & 0xffffffff)] for i in range(8, 20)])
-    w = 7
-    print("  wave 7 pairs 8..20 (wait, body, hooks, odd):", [[int((st[w, i, 1] - st[w, i, 0]) & 0xffffffff), int((st[w, i, 2] - st[w, i, 1]) & 0xffffffff),
-                                                             int((st[w, i, 3] - st[w, i, 2]) & 0xffffffff), int((st[w, i + 1, 0] - st[w, i, 3]) & 0xffffffff)] for i in range(8, 20)])
+        print(f"ffn_fused C={Cc:4d} M={M:8d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.1f} GB/s (algorithmic)")
 
 
 def bench_stem(B=32, R=1024):
@@ -234,4 +193,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "ffn_stamps": ffn_stamps, "ffn_stamps96": lambda: ffn_stamps(96), "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()

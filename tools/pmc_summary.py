@@ -18,9 +18,9 @@ import sys
 from collections import defaultdict
 
 CLASSES = [  # (class, regex on kernel name); first match wins
-    ("ffn_fused_c384", r"ffn_(fused|persist\d)_kernelILi384E|ffn_(fused|persist\d)_kernel<384"),
-    ("ffn_fused_c192", r"ffn_(fused|persist\d)_kernelILi192E|ffn_(fused|persist\d)_kernel<192"),
-    ("ffn_fused_c96", r"ffn_(fused|persist\d)_kernelILi96E|ffn_(fused|persist\d)_kernel<96"),
+    ("ffn_fused_c384", r"ffn_fused_kernelILi384E|ffn_fused_kernel<384"),
+    ("ffn_fused_c192", r"ffn_fused_kernelILi192E|ffn_fused_kernel<192"),
+    ("ffn_fused_c96", r"ffn_fused_kernelILi96E|ffn_fused_kernel<96"),
     ("dw7_mfma_c64 (C = 192, 384)", r"dw7_mfma_kernelILi4E|dw7_mfma_kernel<4"),
     ("dw7_mfma_c96 (C = 96)", r"dw7_mfma_kernelILi6E|dw7_mfma_kernel<6"),
     ("dw7_s1", r"dwconv_tiled_kernelILi7ELi1ELi1E|dwconv_tiled_kernel<7, 1, 1"),
@@ -77,9 +77,12 @@ def main():
     out = {}
     for cls, ctrs in acc.items():
         out[cls] = {cn: {"per_dispatch": s / n, "dispatches": n, "avg_us": dsum / n / 1e3} for cn, (s, n, dsum) in ctrs.items() if n}
+    # the workload the passes were taken on (tools/run_pmc.sh runs `bench.py` with its defaults): bench.py attaches these counters to a
+    # run only when its own workload is the same
+    out["_meta"] = json.loads(os.environ.get("FVHD_PMC_META", '{"res": 1024, "batch": 32, "hidden": 896}'))
     json_path = os.path.join("profiles", f"{tag}_pmc_summary.json")
     json.dump(out, open(json_path, "w"), indent=1, sort_keys=True)
-    print(f"# PMC summary {tag} (rocprofv3 --pmc, one pass per counter group, FVHD_DUAL=0, B = 32 @1024^2; tools/run_pmc.sh + tools/pmc_summary.py)\n")
+    print(f"# PMC summary {tag} (rocprofv3 --pmc, one pass per counter group, B = 32 @1024^2; tools/run_pmc.sh + tools/pmc_summary.py)\n")
     print("Per kernel class, per dispatch.  HBM read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; MFMA busy = "
           "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch cycles), dispatch cycles from GRBM_GUI_ACTIVE when collected (else 2.0 GHz x duration).\n")
     print("| class | dispatches | avg us (trace) | HBM read MB | HBM write MB | HBM GB/s | MFMA busy % | clock GHz | LDS bank-conflict % | wave-cycles: active / issue-stall / waitcnt % |")

@@ -4,10 +4,10 @@
 # The databases (~75 MB) stay on the box (gpurun merges at most 64 MiB back): they are summarised there into
 #     gpurun_out/r02_pmc_summary.{md,json} and gpurun_out/r02_kernel_trace_stats_single_stream.md  -> copy those into profiles/.
 # Separate passes per MI355X_MICROARCH.md "rocprofv3 PMC slots" (FETCH_SIZE = 3 TCC slots, WRITE_SIZE = 2: not in one pass);
-# --kernel-trace only beside --pmc (gpurun refuses sys/runtime traces with counters).  One launch at a time: FVHD_DUAL=0.
+# --kernel-trace only beside --pmc (gpurun refuses sys/runtime traces with counters).
 set -u
 TAG=${1:-r02}
-export FVHD_DUAL=0 TMPDIR=/tmp
+export TMPDIR=/tmp
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
 mkdir -p gpurun_out
 run() { # name, extra rocprofv3 args...
