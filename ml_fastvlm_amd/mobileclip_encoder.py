@@ -256,19 +256,23 @@ class MobileCLIPVisionTower(nn.Module):
         return self._encode(images)
 
     # ---- the projector on the library's GEMM kernels (llava_arch.py:143) ----------------------------
-    def _bind_projector(self, ctx, projector: nn.Module) -> int:
-        """Hand the `mlp2x_gelu` weights (multimodal_projector/builder.py:23-30) to the context once per (storage, version); returns H."""
+    def _check_projector(self, projector: nn.Module):
+        """shape check of the `mlp2x_gelu` weights (multimodal_projector/builder.py:23-30) - before the library is touched"""
         w0, b0, w2, b2 = projector[0].weight, projector[0].bias, projector[2].weight, projector[2].bias
         hid = w0.shape[0]
         if w0.dim() != 2 or w0.shape[1] != self.hidden_size or tuple(w2.shape) != (hid, hid) \
                 or tuple(b0.shape) != (hid,) or tuple(b2.shape) != (hid,):
             raise ValueError(f"mlp2x_gelu projector must be Linear({self.hidden_size}, H) -> GELU -> Linear(H, H); got weights "
                              f"{tuple(w0.shape)}, {tuple(w2.shape)}")
-        src = tuple((t.data_ptr(), t._version, t.dtype) for t in (w0, b0, w2, b2))
+        return w0, b0, w2, b2
+
+    def _bind_projector(self, ctx, weights) -> int:
+        """hand the projector weights to the context once per (storage, version); returns H"""
+        src = tuple((t.data_ptr(), t._version, t.dtype) for t in weights)
         if self._projector_src != src:
-            ctx.set_projector(w0, b0, w2, b2)
+            ctx.set_projector(*weights)
             self._projector_src = src
-        return hid
+        return weights[0].shape[0]
 
     def project(self, tokens: torch.Tensor, projector: nn.Module) -> torch.Tensor:
         """`mm_projector(image_features)` (llava_arch.py:143) for tokens that are ALREADY encoded - the gather-before-projector leg of the
@@ -278,11 +282,12 @@ class MobileCLIPVisionTower(nn.Module):
             if not isinstance(tokens, torch.Tensor) or tokens.dim() < 2 or tokens.shape[-1] != self.hidden_size or tokens.numel() == 0:
                 raise ValueError(f"expected tokens of shape [..., {self.hidden_size}], got "
                                  f"{tuple(tokens.shape) if isinstance(tokens, torch.Tensor) else type(tokens)}")
+            weights = self._check_projector(projector)
             tokens = tokens.to(device=self.device).contiguous()
             if tokens.dtype not in (torch.float32, torch.float16, torch.bfloat16):
                 tokens = tokens.float()
             ctx = self._context()
-            hid = self._bind_projector(ctx, projector)
+            hid = self._bind_projector(ctx, weights)
             rows = tokens.numel() // tokens.shape[-1]
             self._grow(ctx, -(-rows // ctx.num_tokens))
             out = torch.empty(tuple(tokens.shape[:-1]) + (hid,), device=tokens.device, dtype=tokens.dtype)
@@ -293,8 +298,9 @@ class MobileCLIPVisionTower(nn.Module):
     def encode_images_with_projector(self, images: torch.Tensor, projector: nn.Module) -> torch.Tensor:
         with torch.no_grad():
             images = self._check_images(images)
+            weights = self._check_projector(projector)
             ctx = self._context()
-            hid = self._bind_projector(ctx, projector)
+            hid = self._bind_projector(ctx, weights)
             self._grow(ctx, images.shape[0])
             out = torch.empty((images.shape[0], ctx.num_tokens, hid), device=images.device, dtype=images.dtype)
             ctx.encode_images(images, out)
