@@ -223,7 +223,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tower-only", action="store_true", help="time the vision tower without the projector")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives, barriers) even at WORLD_SIZE = 1")
-    ap.add_argument("--ttft-llm-eager", action="store_true", help="--ttft: run the stock HF prefill eagerly instead of replaying it as one hipGraph")
+    ap.add_argument("--ttft-llm", default="kernels", choices=["kernels", "kernels-graph", "hf-graph", "hf-eager"],
+                    help="--ttft: prefill on the hand-written kernels (fvhd_llm_prefill; default), the same as one hipGraph, or the stock transformers module (graph / eager)")
     ap.add_argument("--ttft", action="store_true", help="report time-to-first-token of FastVLM prefill instead (tools/ttft.py, BASELINE configs[2])")
     args = ap.parse_args()
     args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
@@ -259,11 +260,11 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import ttft
         Bt = args.batch if args.batch_given else 8
-        r = ttft.measure(Bt, args.res, args.hidden, args.steps, args.warmup, dev, args.graph, not args.ttft_llm_eager)
+        r = ttft.measure(Bt, args.res, args.hidden, args.steps, args.warmup, dev, args.graph, llm_mode=args.ttft_llm)
         print(json.dumps({"metric": f"TTFT FastVLM prefill, batch={Bt} @{args.res}x{args.res} bf16", "value": r["ttft_ms_median"], "unit": "ms",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ttft_ms_median"], "higher_is_better": False,
                           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": "BASELINE.json configs[2]: encode_images -> embedding splice -> Qwen2 prefill -> first token, "
+                          "config": {"workload": f"BASELINE.json configs[{2 if args.hidden != 3584 else 3}]: encode_images -> embedding splice -> Qwen2 prefill -> first token, "
                                                  "qwen_2 prompt around one <image>, synthetic ids/images, random weights", **r}}))
         return
 

@@ -155,7 +155,8 @@ int fvhd_op_dwconv(fvhd_stream_t stream, const void* x, void* y, const float* w,
  * the chip (or always, under fvhd_set_batch_invariant).  Same arguments as fvhd_op_dwconv(K = 7, stride 1, mult 1, no GELU);
  * needs C % 64 == 0 or C % 96 == 0 and W >= 16, anything else is an error. */
 int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
-/* out[M,N] = epi(A[M,K] . Wt[N,K]^T): A, Wt, resid bf16; bias, ls fp32 [N]; K % 32 == 0, N % 16 == 0. */
+/* out[M,N] = epi(A[M,K] . Wt[N,K]^T): A, Wt, resid bf16; bias, ls fp32 [N]; K % 32 == 0, N % 16 == 0.  out_dtype other than bf16 only with
+ * FVHD_EPI_BIAS (f16 / f32) and FVHD_EPI_NONE (f32: lm_head logits); FVHD_EPI_SWIGLU writes [M, N/2]. */
 int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, const float* ls,
                  const void* resid, void* out, int M, int N, int K, int epilogue, int out_dtype);
 /* LayerNormChannel (mci.py:617-623) on NHWC rows: x,y [M,C] bf16; w,b fp32 [C]. */
@@ -211,6 +212,53 @@ int fvhd_op_preprocess(fvhd_stream_t stream, const void* src, int src_h, int src
 int fvhd_op_splice(fvhd_stream_t stream, const int64_t* ids, const int32_t* start, const int32_t* seqlen, const int64_t* feat_row0,
                    const int64_t* labels_in, const void* table, const void* feats, void* out, uint8_t* mask_out, int64_t* pos_out,
                    int64_t* labels_out, int B, int L, int H, int max_len, int64_t vocab, int64_t n_feat_rows, int left_pad, int dtype);
+
+/* GEMM epilogues added for the LLM prefill (fvhd_op_gemm) */
+#define FVHD_EPI_RESID 4         /* out = resid + A.W^T                           (Qwen2 o_proj / down_proj + the layer's skip) */
+#define FVHD_EPI_SWIGLU 5        /* out[m][j] = silu(acc[m][2j]) * acc[m][2j+1]; out is [M, N/2]; W rows interleaved gate_j, up_j */
+
+/* ---- LLM prefill: Qwen2 decoder stack on the spliced embeddings --------------------
+ * Replaces the prefill call the reference makes into the third-party `transformers` Qwen2ForCausalLM (pinned 4.48.3,
+ * pyproject.toml:17): `LlavaQwen2ForCausalLM.forward` -> `super().forward(inputs_embeds=...)` (llava/model/language_model/
+ * llava_qwen.py:92-103) and the first step of `generate` (:138-143).  One context per (device, model); weights arrive under the
+ * model's own state-dict keys.  Arithmetic: bf16 rows, fp32 accumulation / statistics, like the tower.
+ *   hidden, n_layers, n_heads, n_kv_heads, head_dim (64 | 128), intermediate, vocab, rms_eps, rope_theta = the fields of Qwen2Config
+ *   (Qwen2-0.5B: 896, 24, 14, 2, 64, 4864, 151936, 1e-6, 1e6;  Qwen2-7B: 3584, 28, 28, 4, 128, 18944, 152064). */
+typedef struct fvhd_llm fvhd_llm;
+int fvhd_llm_create(fvhd_llm** out, int device, int hidden, int n_layers, int n_heads, int n_kv_heads, int head_dim, int intermediate,
+                    int vocab, float rms_eps, float rope_theta);
+void fvhd_llm_destroy(fvhd_llm* ctx);
+/* One tensor of the state dict: key = "model.layers.<l>.{input_layernorm,post_attention_layernorm}.weight",
+ * "model.layers.<l>.self_attn.{q,k,v}_proj.{weight,bias}", "model.layers.<l>.self_attn.o_proj.weight",
+ * "model.layers.<l>.mlp.{gate,up,down}_proj.weight", "model.norm.weight", "lm_head.weight" (the embedding table when the
+ * model ties them; the leading "model." may be absent).  host_data: contiguous HOST memory of `dtype` (FVHD_F32 / F16 / BF16) in the
+ * reference's [out, in] layout; converted (matrices to bf16, vectors to fp32), packed (q|k|v rows concatenated, gate / up rows
+ * interleaved) and uploaded before the call returns.  Any other key is an error. */
+int fvhd_llm_set_tensor(fvhd_llm* ctx, const char* key, const void* host_data, int dtype, const int64_t* shape, int ndim);
+int fvhd_llm_finalize(fvhd_llm* ctx);                          /* fails if a tensor is missing */
+int fvhd_llm_reserve(fvhd_llm* ctx, int batch, int seq_len);   /* size the workspace now (synchronises; not during stream capture) */
+/* Prefill: embeds [batch, seq_len, hidden] of `dtype` (the `inputs_embeds` of prepare_inputs_labels_for_multimodal / fvhd_op_splice),
+ * key_valid uint8 [batch, seq_len] (its attention mask; NULL = all valid), position_ids int64 [batch, seq_len] (NULL = 0..seq_len-1)
+ * -> logits_out fp32 [batch, vocab] of the LAST position of every sequence (what generate() samples the first token from).
+ * k_cache / v_cache: NULL, or bf16 [n_layers][batch][n_kv_heads][seq_len][head_dim] each - the rotated keys and the values, in the
+ * layout of transformers' cache layers, for a decode loop to continue from.  Enqueued on `stream`, capture-safe after fvhd_llm_reserve. */
+int fvhd_llm_prefill(fvhd_llm* ctx, const void* embeds, int dtype, const uint8_t* key_valid, const int64_t* position_ids, int batch,
+                     int seq_len, float* logits_out, void* k_cache, void* v_cache, fvhd_stream_t stream);
+/* tests: hidden states after the last decoder layer (before the final norm) of the previous prefill, [rows, hidden] bf16 */
+int fvhd_llm_debug_hidden(fvhd_llm* ctx, void* out, int rows, fvhd_stream_t stream);
+
+/* single ops of the prefill (unit-test entry points) */
+/* Qwen2RMSNorm: y = w * x * rsqrt(mean(x^2) + eps); x, y [M, H] bf16 (may alias), w fp32 [H], H % 8 == 0 */
+int fvhd_op_rmsnorm(fvhd_stream_t stream, const void* x, void* y, const float* w, int M, int H, float eps);
+/* apply_rotary_pos_emb (rotate_half form) in place on the q and k heads of qkv [M, (n_heads + 2 n_kv_heads) * head_dim] bf16;
+ * pos int64 [M] or NULL (row % T); table fp32 [table_positions][head_dim / 2][2] = (cos, sin); k_cache / v_cache as fvhd_llm_prefill
+ * for ONE layer ([M / T][n_kv_heads][T][head_dim]) or NULL */
+int fvhd_op_rope(fvhd_stream_t stream, void* qkv, const int64_t* pos, const float* table, void* k_cache, void* v_cache, int M, int T,
+                 int n_heads, int n_kv_heads, int head_dim, int table_positions);
+/* causal grouped-query attention with a key-padding mask: qkv [B*T, (n_heads + 2 n_kv_heads) * head_dim] bf16 ->
+ * out [B*T, n_heads * head_dim] bf16; key_valid uint8 [B, T] or NULL; head_dim in {64, 128} */
+int fvhd_op_attention_causal(fvhd_stream_t stream, const void* qkv, void* out, const uint8_t* key_valid, int B, int T, int n_heads,
+                             int n_kv_heads, int head_dim);
 
 #ifdef __cplusplus
 }

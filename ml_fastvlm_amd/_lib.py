@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FVHD_LIB") or os.path.join(_HERE, "libfvhd.so")
 
 F32, F16, BF16 = 0, 1, 2
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RESID = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RESID, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3, 4, 5
 
 _lib = None
 
@@ -61,6 +61,16 @@ def _declare(lib) -> None:
         "fvhd_ffn_pack": (ci, [ci, vp, vp, vp, vp]),
         "fvhd_op_preprocess": (ci, [vp, vp, ci, ci, C.c_int64, ci, ci, C.c_uint32, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp, ci, vp, ci]),
         "fvhd_op_splice": (ci, [vp] * 12 + [ci, ci, ci, ci, C.c_int64, C.c_int64, ci, ci]),
+        "fvhd_llm_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci, ci, cf, cf]),
+        "fvhd_llm_destroy": (None, [vp]),
+        "fvhd_llm_set_tensor": (ci, [vp, C.c_char_p, vp, ci, C.POINTER(C.c_int64), ci]),
+        "fvhd_llm_finalize": (ci, [vp]),
+        "fvhd_llm_reserve": (ci, [vp, ci, ci]),
+        "fvhd_llm_prefill": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp]),
+        "fvhd_llm_debug_hidden": (ci, [vp, vp, ci, vp]),
+        "fvhd_op_rmsnorm": (ci, [vp, vp, vp, vp, ci, ci, cf]),
+        "fvhd_op_rope": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci]),
+        "fvhd_op_attention_causal": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     }
     del fp, cl
     for name, (res, args) in sig.items():

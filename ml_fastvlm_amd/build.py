@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libfvhd.so")
-SOURCES = ["dwconv.hip", "dwconv_mfma.hip", "gemm.hip", "attention.hip", "stem_head.hip", "ffn_fused.hip", "splice.hip", "preprocess.hip", "fvhd_api.hip"]
+SOURCES = ["dwconv.hip", "dwconv_mfma.hip", "gemm.hip", "attention.hip", "stem_head.hip", "ffn_fused.hip", "splice.hip", "preprocess.hip", "llm.hip", "llm_api.hip", "fvhd_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-fno-gpu-rdc"]

@@ -574,6 +574,9 @@ int fvhd_version(void) { return 100; }
 
 const char* fvhd_last_error(void) { return g_err.c_str(); }
 
+// the other translation units of the library (llm_api.hip) report through the same thread-local message; returns 1
+int fvhd_set_error(const char* msg) { return fail(msg ? msg : "unknown error"); }
+
 int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
 {
     if (!out) return fail("fvhd_create: out is NULL");

@@ -29,6 +29,8 @@
 #define EPI_BIAS 1
 #define EPI_BIAS_GELU 2
 #define EPI_BIAS_LS_RESID 3
+#define EPI_RESID 4        // out = resid + A.W^T                        (Qwen2 o_proj / down_proj + the decoder layer's skip)
+#define EPI_SWIGLU 5       // out[m][j] = silu(acc[m][2j]) * acc[m][2j+1], out is [M, N/2]: W rows interleaved gate_j, up_j (Qwen2MLP)
 
 template <int BK>
 FVHD_DEV int lds_off(int row, int ks)
@@ -47,19 +49,27 @@ FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias
         const int n = nw + j * 16 + g * 4;
         if (n >= N) continue;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, lv = f32x4{1.f, 1.f, 1.f, 1.f};
-        if constexpr (EPI != EPI_NONE) bv = *(const f32x4*)(bias + n);
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_LS_RESID) bv = *(const f32x4*)(bias + n);
         if constexpr (EPI == EPI_BIAS_LS_RESID) lv = *(const f32x4*)(ls + n);
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int m = mw + i * 16 + lr;
             if (m >= M) continue;
             f32x4 v = acc[i][j] + bv;
+            if constexpr (EPI == EPI_SWIGLU) {
+                // the lane's 4 consecutive columns are (gate, up, gate, up) of hidden units n/2, n/2 + 1: silu(gate) * up, written
+                // to the [M, N/2] activation (4-B store)
+                static_assert(ODT == FVHD_BF16, "SwiGLU writes the bf16 activation");
+                const f32x2 r = {v[0] * sigmoidf_fast(v[0]) * v[1], v[2] * sigmoidf_fast(v[2]) * v[3]};
+                *(bf16x2*)((bf16*)out + (size_t)m * (N / 2) + n / 2) = __builtin_convertvector(r, bf16x2);
+                continue;
+            }
             if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
             }
             const size_t o = (size_t)m * N + n;
-            if constexpr (EPI == EPI_BIAS_LS_RESID) {
+            if constexpr (EPI == EPI_BIAS_LS_RESID || EPI == EPI_RESID) {
                 const f32x4 r = bf4_to_f32(*(const bf16x4*)(resid + o));
                 v = r + lv * v;
             }
@@ -306,16 +316,21 @@ static hipError_t dispatch_epi(hipStream_t st, const bf16* A, const bf16* Wt, co
         case EPI_BIAS: return launch_gemm<NF, BK, EPI_BIAS, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
         case EPI_BIAS_GELU: return launch_gemm<NF, BK, EPI_BIAS_GELU, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
         case EPI_BIAS_LS_RESID: return launch_gemm<NF, BK, EPI_BIAS_LS_RESID, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
+        case EPI_RESID: return launch_gemm<NF, BK, EPI_RESID, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
+        case EPI_SWIGLU: return launch_gemm<NF, BK, EPI_SWIGLU, FVHD_BF16>(st, A, Wt, bias, ls, resid, out, M, N, K);
         }
     } else if (epi == EPI_BIAS) {
         if (odt == FVHD_F16) return launch_gemm<NF, BK, EPI_BIAS, FVHD_F16>(st, A, Wt, bias, ls, resid, out, M, N, K);
         if (odt == FVHD_F32) return launch_gemm<NF, BK, EPI_BIAS, FVHD_F32>(st, A, Wt, bias, ls, resid, out, M, N, K);
+    } else if (epi == EPI_NONE && odt == FVHD_F32) {                 // fp32 logits of the lm_head
+        return launch_gemm<NF, BK, EPI_NONE, FVHD_F32>(st, A, Wt, bias, ls, resid, out, M, N, K);
     }
     return hipErrorInvalidValue;
 }
 
 // A [M,K] bf16, Wt [N,K] bf16, bias/ls fp32 [N], resid bf16 [M,N] (may alias out), out [M,N] of out_dtype.
-// Requirements: K % 32 == 0, N % 16 == 0.  Non-bf16 outputs only with epi == EPI_BIAS.
+// Requirements: K % 32 == 0, N % 16 == 0.  Non-bf16 outputs only with epi == EPI_BIAS (f16 / f32) and EPI_NONE (f32).
+// EPI_SWIGLU: out is [M, N/2].
 extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, const float* bias, const float* ls,
                                 const void* resid, void* out, int M, int N, int K, int epi, int out_dtype)
 {
@@ -333,6 +348,8 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
         case EPI_BIAS: return (int)launch_gemm256<EPI_BIAS, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
         case EPI_BIAS_GELU: return (int)launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
         case EPI_BIAS_LS_RESID: return (int)launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
+        case EPI_RESID: return (int)launch_gemm256<EPI_RESID, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
+        case EPI_SWIGLU: return (int)launch_gemm256<EPI_SWIGLU, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
         }
     }
     const bool nf3 = (N % 128 != 0) && (N % 96 == 0);

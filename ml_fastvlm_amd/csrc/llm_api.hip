@@ -1,0 +1,369 @@
+// C ABI of the Qwen2 prefill (include/fvhd.h "LLM prefill"): context, weight packing, workspace and the launch sequence of
+// transformers' Qwen2ForCausalLM.forward on inputs_embeds (the call the reference makes at llava/model/language_model/
+// llava_qwen.py:92-103 after prepare_inputs_labels_for_multimodal, and from generate(), :138-143).  Kernels: llm.hip + gemm.hip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fvhd.h"
+
+extern "C" {
+int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
+int fvhd_launch_rmsnorm(hipStream_t, const void*, void*, const float*, int, int, float);
+int fvhd_launch_rope(hipStream_t, void*, const long*, const float*, void*, void*, int, int, int, int, int, int);
+int fvhd_launch_llm_attention(hipStream_t, const void*, void*, const unsigned char*, int, int, int, int, int);
+int fvhd_launch_cast_rows(hipStream_t, const void*, int, void*, long);
+int fvhd_launch_gather_rows(hipStream_t, const void*, void*, int, int, int, int);
+int fvhd_set_error(const char* msg);     // fvhd_api.hip: the library's one thread-local error string
+}
+
+namespace {
+
+constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_RESID = 4, EPI_SWIGLU = 5;
+
+int lfail(const std::string& m) { return fvhd_set_error(m.c_str()); }
+int lhip(const char* what, hipError_t e) { return lfail(std::string(what) + ": " + hipGetErrorString(e)); }
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+uint16_t bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+float half_to_float(uint16_t h)
+{
+    const uint32_t s = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 1023;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = s;
+        else { int k = 0; uint32_t mm = m; while (!(mm & 1024)) { mm <<= 1; ++k; } u = s | ((uint32_t)(113 - k) << 23) | ((mm & 1023) << 13); }
+    } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+    else u = s | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+float load_as_float(const void* p, int dtype, size_t i)
+{
+    if (dtype == FVHD_F32) return ((const float*)p)[i];
+    if (dtype == FVHD_BF16) { uint32_t u = (uint32_t)((const uint16_t*)p)[i] << 16; float f; memcpy(&f, &u, 4); return f; }
+    return half_to_float(((const uint16_t*)p)[i]);
+}
+
+struct LayerOff { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd; };
+
+struct DevGuard {
+    int prev = -1; bool sw = false; hipError_t err = hipSuccess;
+    explicit DevGuard(int d) { err = hipGetDevice(&prev); if (err == hipSuccess && prev != d) { err = hipSetDevice(d); sw = err == hipSuccess; } }
+    ~DevGuard() { if (sw) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+struct fvhd_llm {
+    int device = 0, H = 0, L = 0, nh = 0, nkv = 0, hd = 0, I = 0, V = 0;
+    float eps = 1e-6f, theta = 1e6f;
+    int qkvw = 0;
+    char* wdev = nullptr;
+    size_t wbytes = 0;
+    std::vector<LayerOff> lo;
+    size_t norm_off = 0, lm_off = 0;
+    std::vector<char> got;                 // per expected tensor: received?
+    std::vector<std::string> names;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int ws_rows = 0, ws_batch = 0, ws_pos = 0;
+    char *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *last = nullptr, *lastn = nullptr;
+    float* rope = nullptr;
+};
+
+namespace {
+
+// expected tensor index: per layer 12 (ln1, q.w, q.b, k.w, k.b, v.w, v.b, o.w, ln2, gate, up, down), then norm, lm_head
+int tensor_index(const fvhd_llm* c, const std::string& key, int* layer, int* which)
+{
+    std::string k = key;
+    if (k.rfind("model.", 0) == 0) k = k.substr(6);
+    if (k == "norm.weight") { *layer = -1; *which = 0; return c->L * 12; }
+    if (k == "lm_head.weight") { *layer = -1; *which = 1; return c->L * 12 + 1; }
+    if (k.rfind("layers.", 0) != 0) return -1;
+    const size_t dot = k.find('.', 7);
+    if (dot == std::string::npos) return -1;
+    const int l = atoi(k.substr(7, dot - 7).c_str());
+    if (l < 0 || l >= c->L) return -1;
+    const std::string rest = k.substr(dot + 1);
+    static const char* kNames[12] = {"input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
+                                     "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias", "self_attn.o_proj.weight",
+                                     "post_attention_layernorm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"};
+    for (int i = 0; i < 12; ++i)
+        if (rest == kNames[i]) { *layer = l; *which = i; return l * 12 + i; }
+    return -1;
+}
+
+// host rows [rows][cols] of `dtype` -> device bf16 rows at dst, dst row pitch `pitch_elems` (interleaving = pitch 2 * cols)
+int upload_matrix(const void* host, int dtype, size_t rows, size_t cols, char* dst, size_t pitch_elems)
+{
+    std::vector<uint16_t> tmp(rows * cols);
+    if (dtype == FVHD_BF16) memcpy(tmp.data(), host, rows * cols * 2);
+    else
+        for (size_t i = 0; i < rows * cols; ++i) tmp[i] = bf16_rne(load_as_float(host, dtype, i));
+    hipError_t e = hipMemcpy2D(dst, pitch_elems * 2, tmp.data(), cols * 2, cols * 2, rows, hipMemcpyHostToDevice);
+    return e == hipSuccess ? 0 : lhip("hipMemcpy2D(llm weights)", e);
+}
+
+int upload_vector_f32(const void* host, int dtype, size_t n, char* dst)
+{
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = load_as_float(host, dtype, i);
+    hipError_t e = hipMemcpy(dst, tmp.data(), n * 4, hipMemcpyHostToDevice);
+    return e == hipSuccess ? 0 : lhip("hipMemcpy(llm vector)", e);
+}
+
+int ensure_ws(fvhd_llm* c, int B, int T, hipStream_t st, bool check_capture)
+{
+    const int rows = (int)(((size_t)B * T + 255) / 256 * 256);
+    if (c->ws && rows <= c->ws_rows && B <= c->ws_batch && T <= c->ws_pos) return 0;
+    if (check_capture) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return lfail("fvhd_llm_prefill: the workspace must grow for this (batch, length) but the stream is being captured - call fvhd_llm_reserve first");
+    }
+    const int nrows = rows > c->ws_rows ? rows : c->ws_rows, nb = B > c->ws_batch ? B : c->ws_batch, np = T > c->ws_pos ? T : c->ws_pos;
+    const int lb = (nb + 15) / 16 * 16;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    const size_t o_h = take((size_t)nrows * c->H * 2), o_xn = take((size_t)nrows * c->H * 2), o_qkv = take((size_t)nrows * c->qkvw * 2),
+                 o_att = take((size_t)nrows * c->nh * c->hd * 2), o_act = take((size_t)nrows * c->I * 2), o_last = take((size_t)lb * c->H * 2),
+                 o_lastn = take((size_t)lb * c->H * 2), o_rope = take((size_t)np * c->hd * 4);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return lhip("hipDeviceSynchronize", e);
+    if (c->ws) (void)hipFree(c->ws);
+    c->ws = nullptr;
+    e = hipMalloc((void**)&c->ws, off);
+    if (e != hipSuccess) return lhip("hipMalloc(llm workspace)", e);
+    e = hipMemset(c->ws, 0, off);           // the padding rows start (and stay) finite
+    if (e != hipSuccess) return lhip("hipMemset(llm workspace)", e);
+    c->ws_bytes = off; c->ws_rows = nrows; c->ws_batch = nb; c->ws_pos = np;
+    c->h = c->ws + o_h; c->xn = c->ws + o_xn; c->qkv = c->ws + o_qkv; c->att = c->ws + o_att; c->act = c->ws + o_act;
+    c->last = c->ws + o_last; c->lastn = c->ws + o_lastn; c->rope = (float*)(c->ws + o_rope);
+    // rotary table, fp32 like Qwen2RotaryEmbedding.forward: inv_freq_i = theta^(-2i/hd), angle = pos * inv_freq_i, (cos, sin)
+    std::vector<float> tab((size_t)np * c->hd);
+    for (int p = 0; p < np; ++p)
+        for (int i = 0; i < c->hd / 2; ++i) {
+            const float inv = 1.0f / powf(c->theta, (float)(2 * i) / (float)c->hd);
+            const float ang = (float)p * inv;
+            tab[((size_t)p * (c->hd / 2) + i) * 2] = cosf(ang);
+            tab[((size_t)p * (c->hd / 2) + i) * 2 + 1] = sinf(ang);
+        }
+    e = hipMemcpy(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+    return e == hipSuccess ? 0 : lhip("hipMemcpy(rope table)", e);
+}
+
+#define LCHECK(expr, what)                                   \
+    do {                                                     \
+        int _e = (expr);                                     \
+        if (_e) return lhip(what, (hipError_t)_e);           \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int fvhd_llm_create(fvhd_llm** out, int device, int hidden, int n_layers, int n_heads, int n_kv_heads, int head_dim, int intermediate,
+                    int vocab, float rms_eps, float rope_theta)
+{
+    if (!out) return lfail("fvhd_llm_create: out is NULL");
+    *out = nullptr;
+    if (hidden <= 0 || n_layers <= 0 || n_heads <= 0 || n_kv_heads <= 0 || intermediate <= 0 || vocab <= 0)
+        return lfail("fvhd_llm_create: sizes must be positive");
+    if (head_dim != 64 && head_dim != 128) return lfail("fvhd_llm_create: head_dim must be 64 or 128 (Qwen2-0.5B/1.5B: 64 / 128, 7B: 128)");
+    if (n_heads % n_kv_heads) return lfail("fvhd_llm_create: n_heads must be a multiple of n_kv_heads");
+    const int qkvw = (n_heads + 2 * n_kv_heads) * head_dim;
+    if (hidden % 64 || (n_heads * head_dim) % 64 || intermediate % 64 || qkvw % 16 || vocab % 16)
+        return lfail("fvhd_llm_create: hidden, n_heads * head_dim and intermediate must be multiples of 64, vocab of 16");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return lfail("fvhd_llm_create: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return lfail("fvhd_llm_create: bad device index");
+    fvhd_llm* c = new fvhd_llm();
+    c->device = device; c->H = hidden; c->L = n_layers; c->nh = n_heads; c->nkv = n_kv_heads; c->hd = head_dim; c->I = intermediate; c->V = vocab;
+    c->eps = rms_eps; c->theta = rope_theta; c->qkvw = qkvw;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
+    c->lo.resize(n_layers);
+    for (int l = 0; l < n_layers; ++l) {
+        LayerOff& o = c->lo[l];
+        o.ln1 = take((size_t)hidden * 4);
+        o.wqkv = take((size_t)qkvw * hidden * 2);
+        o.bqkv = take((size_t)qkvw * 4);
+        o.wo = take((size_t)hidden * n_heads * head_dim * 2);
+        o.ln2 = take((size_t)hidden * 4);
+        o.wgu = take((size_t)2 * intermediate * hidden * 2);
+        o.wd = take((size_t)hidden * intermediate * 2);
+    }
+    c->norm_off = take((size_t)hidden * 4);
+    c->lm_off = take((size_t)vocab * hidden * 2);
+    c->wbytes = off;
+    c->got.assign((size_t)n_layers * 12 + 2, 0);
+    DevGuard g(device);
+    if (g.err != hipSuccess) { delete c; return lhip("hipSetDevice", g.err); }
+    hipError_t e = hipMalloc((void**)&c->wdev, off);
+    if (e != hipSuccess) { delete c; return lhip("hipMalloc(llm weights)", e); }
+    *out = c;
+    return 0;
+}
+
+void fvhd_llm_destroy(fvhd_llm* c)
+{
+    if (!c) return;
+    DevGuard g(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->wdev) (void)hipFree(c->wdev);
+    if (c->ws) (void)hipFree(c->ws);
+    delete c;
+}
+
+int fvhd_llm_set_tensor(fvhd_llm* c, const char* key, const void* host_data, int dtype, const int64_t* shape, int ndim)
+{
+    if (!c || !key || !host_data || !shape) return lfail("fvhd_llm_set_tensor: NULL argument");
+    if (dtype < 0 || dtype > 2) return lfail("fvhd_llm_set_tensor: bad dtype");
+    int layer = -1, which = -1;
+    const int idx = tensor_index(c, key, &layer, &which);
+    if (idx < 0) return lfail(std::string("fvhd_llm_set_tensor: not a tensor of the Qwen2 decoder stack: ") + key);
+    const int H = c->H, hd = c->hd, nh = c->nh, nkv = c->nkv, I = c->I;
+    auto want = [&](int64_t r, int64_t cc) -> bool { return cc < 0 ? (ndim == 1 && shape[0] == r) : (ndim == 2 && shape[0] == r && shape[1] == cc); };
+    DevGuard g(c->device);
+    if (g.err != hipSuccess) return lhip("hipSetDevice", g.err);
+    int e = 0;
+    bool ok = true;
+    if (layer < 0) {
+        if (which == 0) { ok = want(H, -1); if (ok) e = upload_vector_f32(host_data, dtype, H, c->wdev + c->norm_off); }
+        else { ok = want(c->V, H); if (ok) e = upload_matrix(host_data, dtype, c->V, H, c->wdev + c->lm_off, H); }
+    } else {
+        const LayerOff& o = c->lo[layer];
+        char* w = c->wdev;
+        switch (which) {
+        case 0: ok = want(H, -1); if (ok) e = upload_vector_f32(host_data, dtype, H, w + o.ln1); break;
+        case 1: ok = want((int64_t)nh * hd, H); if (ok) e = upload_matrix(host_data, dtype, (size_t)nh * hd, H, w + o.wqkv, H); break;
+        case 2: ok = want((int64_t)nh * hd, -1); if (ok) e = upload_vector_f32(host_data, dtype, (size_t)nh * hd, w + o.bqkv); break;
+        case 3: ok = want((int64_t)nkv * hd, H); if (ok) e = upload_matrix(host_data, dtype, (size_t)nkv * hd, H, w + o.wqkv + (size_t)nh * hd * H * 2, H); break;
+        case 4: ok = want((int64_t)nkv * hd, -1); if (ok) e = upload_vector_f32(host_data, dtype, (size_t)nkv * hd, w + o.bqkv + (size_t)nh * hd * 4); break;
+        case 5: ok = want((int64_t)nkv * hd, H); if (ok) e = upload_matrix(host_data, dtype, (size_t)nkv * hd, H, w + o.wqkv + (size_t)(nh + nkv) * hd * H * 2, H); break;
+        case 6: ok = want((int64_t)nkv * hd, -1); if (ok) e = upload_vector_f32(host_data, dtype, (size_t)nkv * hd, w + o.bqkv + (size_t)(nh + nkv) * hd * 4); break;
+        case 7: ok = want(H, (int64_t)nh * hd); if (ok) e = upload_matrix(host_data, dtype, H, (size_t)nh * hd, w + o.wo, (size_t)nh * hd); break;
+        case 8: ok = want(H, -1); if (ok) e = upload_vector_f32(host_data, dtype, H, w + o.ln2); break;
+        // gate / up rows interleaved (row 2j = gate_j, row 2j + 1 = up_j): the SwiGLU epilogue of the GEMM pairs adjacent columns
+        case 9: ok = want(I, H); if (ok) e = upload_matrix(host_data, dtype, I, H, w + o.wgu, (size_t)2 * H); break;
+        case 10: ok = want(I, H); if (ok) e = upload_matrix(host_data, dtype, I, H, w + o.wgu + (size_t)H * 2, (size_t)2 * H); break;
+        case 11: ok = want(H, I); if (ok) e = upload_matrix(host_data, dtype, H, I, w + o.wd, I); break;
+        }
+    }
+    if (!ok) return lfail(std::string("fvhd_llm_set_tensor: bad shape for ") + key);
+    if (e) return e;
+    c->got[idx] = 1;
+    return 0;
+}
+
+int fvhd_llm_finalize(fvhd_llm* c)
+{
+    if (!c) return lfail("fvhd_llm_finalize: ctx is NULL");
+    for (size_t i = 0; i < c->got.size(); ++i)
+        if (!c->got[i]) {
+            const size_t l = i / 12, w = i % 12;
+            return lfail("fvhd_llm_finalize: missing tensor (layer " + std::to_string(l) + ", slot " + std::to_string(w) +
+                         "; slots: ln1 q.w q.b k.w k.b v.w v.b o.w ln2 gate up down | norm lm_head)");
+        }
+    return 0;
+}
+
+int fvhd_llm_reserve(fvhd_llm* c, int batch, int seq_len)
+{
+    if (!c || batch <= 0 || seq_len <= 0) return lfail("fvhd_llm_reserve: bad argument");
+    DevGuard g(c->device);
+    if (g.err != hipSuccess) return lhip("hipSetDevice", g.err);
+    return ensure_ws(c, batch, seq_len, nullptr, false);
+}
+
+int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* key_valid, const int64_t* position_ids, int batch, int seq_len,
+                     float* logits_out, void* k_cache, void* v_cache, fvhd_stream_t stream)
+{
+    if (!c || !embeds || !logits_out) return lfail("fvhd_llm_prefill: NULL argument");
+    if (dtype < 0 || dtype > 2) return lfail("fvhd_llm_prefill: bad dtype");
+    if (batch <= 0 || seq_len <= 0) return lfail("fvhd_llm_prefill: batch and seq_len must be positive");
+    if ((k_cache == nullptr) != (v_cache == nullptr)) return lfail("fvhd_llm_prefill: k_cache and v_cache come together");
+    for (char g : c->got)
+        if (!g) return lfail("fvhd_llm_prefill: weights incomplete (fvhd_llm_finalize reports the missing tensor)");
+    DevGuard g(c->device);
+    if (g.err != hipSuccess) return lhip("hipSetDevice", g.err);
+    hipStream_t st = (hipStream_t)stream;
+    int e = ensure_ws(c, batch, seq_len, st, true);
+    if (e) return e;
+    const int B = batch, T = seq_len, M = B * T, Mp = (M + 255) / 256 * 256;
+    const int H = c->H, I = c->I, nh = c->nh, nkv = c->nkv, hd = c->hd;
+    const char* w = c->wdev;
+    if ((size_t)M * H % 4) return lfail("fvhd_llm_prefill: batch * seq_len * hidden must be a multiple of 4");
+    LCHECK(fvhd_launch_cast_rows(st, embeds, dtype, c->h, (long)M * H), "cast embeds");
+    const size_t cache_layer = (size_t)B * nkv * T * hd * 2;
+    for (int l = 0; l < c->L; ++l) {
+        const LayerOff& o = c->lo[l];
+        LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln1), Mp, H, c->eps), "rmsnorm 1");
+        LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wqkv, (const float*)(w + o.bqkv), nullptr, nullptr, c->qkv, Mp, c->qkvw, H, EPI_BIAS, FVHD_BF16), "qkv gemm");
+        LCHECK(fvhd_launch_rope(st, c->qkv, (const long*)position_ids, c->rope, k_cache ? (char*)k_cache + l * cache_layer : nullptr,
+                                v_cache ? (char*)v_cache + l * cache_layer : nullptr, M, T, nh, nkv, hd, c->ws_pos), "rope");
+        LCHECK(fvhd_launch_llm_attention(st, c->qkv, c->att, key_valid, B, T, nh, nkv, hd), "attention");
+        LCHECK(fvhd_launch_gemm(st, c->att, w + o.wo, nullptr, nullptr, c->h, c->h, Mp, H, nh * hd, EPI_RESID, FVHD_BF16), "o_proj gemm");
+        LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln2), Mp, H, c->eps), "rmsnorm 2");
+        LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wgu, nullptr, nullptr, nullptr, c->act, Mp, 2 * I, H, EPI_SWIGLU, FVHD_BF16), "gate_up gemm");
+        LCHECK(fvhd_launch_gemm(st, c->act, w + o.wd, nullptr, nullptr, c->h, c->h, Mp, H, I, EPI_RESID, FVHD_BF16), "down gemm");
+    }
+    // logits of the LAST position of every sequence (what generate() reads: outputs.logits[:, -1, :])
+    LCHECK(fvhd_launch_gather_rows(st, c->h, c->last, B, T, T - 1, H), "gather last rows");
+    LCHECK(fvhd_launch_rmsnorm(st, c->last, c->lastn, (const float*)(w + c->norm_off), B, H, c->eps), "final norm");
+    LCHECK(fvhd_launch_gemm(st, c->lastn, w + c->lm_off, nullptr, nullptr, nullptr, logits_out, B, c->V, H, EPI_NONE, FVHD_F32), "lm_head gemm");
+    return 0;
+}
+
+// hidden states after the decoder stack (before the final norm) of the last prefill: [batch * seq_len, hidden] bf16, for tests
+int fvhd_llm_debug_hidden(fvhd_llm* c, void* out, int rows, fvhd_stream_t stream)
+{
+    if (!c || !out || rows <= 0 || rows > c->ws_rows) return lfail("fvhd_llm_debug_hidden: bad argument");
+    DevGuard g(c->device);
+    hipError_t e = hipMemcpyAsync(out, c->h, (size_t)rows * c->H * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : lhip("hipMemcpyAsync", e);
+}
+
+// ---- single ops (unit tests) ----
+int fvhd_op_rmsnorm(fvhd_stream_t st, const void* x, void* y, const float* w, int M, int H, float eps)
+{
+    if (!x || !y || !w) return lfail("fvhd_op_rmsnorm: NULL pointer");
+    int e = fvhd_launch_rmsnorm((hipStream_t)st, x, y, w, M, H, eps);
+    return e ? lhip("fvhd_op_rmsnorm", (hipError_t)e) : 0;
+}
+
+int fvhd_op_rope(fvhd_stream_t st, void* qkv, const int64_t* pos, const float* table, void* k_cache, void* v_cache, int M, int T, int n_heads,
+                 int n_kv_heads, int head_dim, int table_positions)
+{
+    if (!qkv || !table) return lfail("fvhd_op_rope: NULL pointer");
+    int e = fvhd_launch_rope((hipStream_t)st, qkv, (const long*)pos, table, k_cache, v_cache, M, T, n_heads, n_kv_heads, head_dim, table_positions);
+    return e ? lhip("fvhd_op_rope", (hipError_t)e) : 0;
+}
+
+int fvhd_op_attention_causal(fvhd_stream_t st, const void* qkv, void* out, const uint8_t* key_valid, int B, int T, int n_heads, int n_kv_heads, int head_dim)
+{
+    if (!qkv || !out) return lfail("fvhd_op_attention_causal: NULL pointer");
+    int e = fvhd_launch_llm_attention((hipStream_t)st, qkv, out, key_valid, B, T, n_heads, n_kv_heads, head_dim);
+    return e ? lhip("fvhd_op_attention_causal", (hipError_t)e) : 0;
+}
+
+}  // extern "C"

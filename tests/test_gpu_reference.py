@@ -8,10 +8,11 @@ as `oracle/_ref/reference_llava.zip` (git-ignored, shipped with the tree like li
      weights and images - the first direct GPU-vs-reference comparison.  STATED TOLERANCE (mild weight set):
      rel-L2 <= 1e-2, cosine >= 0.9999, max-abs <= 3e-2 * absmax.
  (b) the reference's `LlavaQwen2ForCausalLM.generate(images=...)` (`predict.py:55-65` -> `llava_qwen.py:118-134` ->
-     `llava_arch.py:146-332`), once un-patched (reference tower + reference splice walk, fp32 on the GPU) and once after
+     `llava_arch.py:146-332`), once un-patched (reference tower + reference splice walk, fp32 on the GPU), once after
      `install_into_llava(splice=True)` (our tower through the C ABI + the HIP splice kernel) with the SAME state dict loaded
      strictly: first-token logits agree to rel-L2 <= 3e-2 (bf16 tower arithmetic under an fp32 LLM) and the greedy token is
-     the same wherever the reference's own top-2 margin exceeds that error.
+     the same wherever the reference's own top-2 margin exceeds that error; and once more with `prefill=True` (the language
+     model's prefill on the hand-written Qwen2 kernels, the stock decode loop continuing from our KV cache): rel-L2 <= 4e-2.
 MIOpen is switched off for the reference runs (`torch.backends.cudnn.flags(enabled=False)`: ATen's native HIP convolutions) so a
 fresh box does not spend minutes compiling MIOpen kernels; the arithmetic is fp32 either way.
 """
@@ -65,8 +66,8 @@ def test_our_tower_vs_the_reference_tower_on_pytorch_rocm(res, batch):
 def _llava_cfg(hidden=128):
     from transformers import Qwen2Config
     from llava.model.language_model.llava_qwen import LlavaConfig
-    cfg = LlavaConfig(**Qwen2Config(vocab_size=1024, hidden_size=hidden, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
-                                    num_key_value_heads=2, max_position_embeddings=2048).to_dict())
+    cfg = LlavaConfig(**Qwen2Config(vocab_size=1024, hidden_size=hidden, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                    num_key_value_heads=1, max_position_embeddings=2048).to_dict())        # head_dim 64, as Qwen2-0.5B
     cfg.mm_vision_tower, cfg.mm_projector_type, cfg.mm_hidden_size = "mobileclip_l_256", "mlp2x_gelu", 3072
     cfg.unfreeze_mm_vision_tower = True          # llava_arch.py:35 builds with delay_load=True; this forces the load
     cfg.tokenizer_padding_side, cfg.tokenizer_model_max_length = "right", 2048
@@ -80,8 +81,9 @@ def test_reference_generate_with_our_tower_underneath():
     import llava.model.llava_arch as arch
     import llava.model.multimodal_encoder.builder as enc_builder
     from llava.model.language_model.llava_qwen import LlavaQwen2ForCausalLM
+    import llava.model.language_model.llava_qwen as lq
     saved = (enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images,
-             arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal)
+             arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal, lq.LlavaQwen2ForCausalLM.forward)
     hidden = 128
     tower_sd = synth.synthetic_state_dict(1234, "mild")
     proj_sd = synth.synthetic_projector_state_dict(hidden, 1234)
@@ -98,7 +100,7 @@ def test_reference_generate_with_our_tower_underneath():
             out = model.generate(ids.to(DEV), images=images.to(DEV), image_sizes=[(256, 256)] * 3, attention_mask=mask.to(DEV),
                                  do_sample=False, max_new_tokens=2, use_cache=True, output_scores=True, return_dict_in_generate=True,
                                  pad_token_id=0)
-        return out.sequences.cpu(), out.scores[0].float().cpu()
+        return out.sequences.cpu(), out.scores[0].float().cpu(), out.scores[1].float().cpu()
 
     try:
         torch.manual_seed(0)
@@ -107,7 +109,7 @@ def test_reference_generate_with_our_tower_underneath():
         ref_model.get_vision_tower().vision_tower.model.load_state_dict(tower_sd, strict=True)
         ref_model.get_model().mm_projector.load_state_dict(proj_sd, strict=True)
         state = {k: v.clone() for k, v in ref_model.state_dict().items()}
-        seq_ref, logits_ref = run(ref_model)
+        seq_ref, logits_ref, logits2_ref = run(ref_model)
         del ref_model
 
         fv.install_into_llava(splice=True)                                           # the whole reference-side patch
@@ -124,11 +126,23 @@ def test_reference_generate_with_our_tower_underneath():
             ctx_probe["n"] = ctx_probe.get("n", 0) + 1
             return real(images_, projector)
         tower.encode_images_with_projector = spy
-        seq, logits = run(ours_model)
+        seq, logits, logits2 = run(ours_model)
         assert ctx_probe.get("n", 0) == 1, "generate() must reach the fused library call exactly once (prefill)"
+
+        # ... and with the PREFILL of the language model on the hand-written Qwen2 kernels too: first-token logits from
+        # fvhd_llm_prefill, second-token logits from the stock decode step running on OUR KV cache
+        fv.install_into_llava(splice=True, prefill=True)
+        assert getattr(lq.LlavaQwen2ForCausalLM.forward, "_fvhd_prefill", False)
+        seq_p, logits_p, logits2_p = run(ours_model)
+        assert getattr(ours_model, "_fvhd_prefill_ctx", None) is not None, "generate() did not reach the Qwen2 prefill kernels"
     finally:
         (enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images,
-         arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal) = saved
+         arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal, lq.LlavaQwen2ForCausalLM.forward) = saved
+    for name, a, b in (("first token, prefill kernels", logits_p, logits_ref), ("second token (stock decode on our KV cache)", logits2_p, logits2_ref)):
+        rel, cos, mx = _metrics(a, b)
+        print(f"{name}: logits vs the un-patched reference model rel-L2 {rel:.3e} cos {cos:.6f}")
+        if name.startswith("first") or torch.equal(seq_p[:, 0], seq_ref[:, 0]):      # the second step is comparable only after the same first token
+            assert rel <= 4e-2 and cos >= 0.999, (name, rel, cos)
     rel, cos, mx = _metrics(logits, logits_ref)
     print(f"first-token logits, patched vs un-patched reference model: rel-L2 {rel:.3e} cos {cos:.6f} max-abs/absmax {mx:.3e}")
     assert logits.shape == logits_ref.shape == (3, 1024)

@@ -1,5 +1,6 @@
-"""TTFT harness (tools/ttft.py, `bench.py --ttft`): the hipGraph-captured prefill must produce the first tokens the eager stock
-module produces on the same spliced embeddings, and the pipeline's pieces must line up (token count, batch)."""
+"""TTFT harness (tools/ttft.py, `bench.py --ttft`): the four prefill modes (hand-written kernels, the same as one hipGraph, the stock
+`transformers` module captured / eager) run on the same spliced embeddings - padded batches included - and line up (token count, batch,
+first tokens)."""
 import os
 import sys
 
@@ -10,22 +11,33 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-def test_ttft_pipeline_graph_equals_eager():
+def test_ttft_pipeline_modes_agree():
     import ttft
     from transformers import Qwen2Config, Qwen2ForCausalLM
     dev = torch.device("cuda", 0)
-    # the real harness with a 2-layer LLM of the 0.5 B width at 256^2 (16 image tokens): both prefill modes
+    # the real harness with a 2-layer LLM of the 0.5 B width at 256^2 (16 image tokens): all four prefill modes, unpadded and with a
+    # LEFT-padded batch (attention mask + position ids must reach the prefill in every mode - VERDICT r2 weak #10)
     small = dict(ttft.QWEN2[896], num_hidden_layers=2)
     orig = ttft.QWEN2[896]
     ttft.QWEN2[896] = small
     try:
-        g = ttft.measure(2, 256, 896, steps=2, warmup=1, dev=dev, llm_graph=True)
-        e = ttft.measure(2, 256, 896, steps=2, warmup=1, dev=dev, llm_graph=False)
+        for pad in (0, 5):
+            r = {m: ttft.measure(2, 256, 896, steps=2, warmup=1, dev=dev, llm_mode=m, pad_left=pad, return_tokens=True)
+                 for m in ("kernels", "kernels-graph", "hf-graph", "hf-eager")}
+            g, e = r["hf-graph"], r["hf-eager"]
+            assert "hipGraph" in g["prefill_mode"] and e["prefill_mode"].endswith("eager")
+            assert "hipGraph" in r["kernels-graph"]["prefill_mode"], r["kernels-graph"]["prefill_mode"]
+            assert g["prompt_tokens"] == e["prompt_tokens"] == ttft.PROMPT_BEFORE + ttft.PROMPT_AFTER + 16
+            assert all(v["ttft_ms_median"] > 0 for v in r.values())
+            assert g["first_tokens"] == e["first_tokens"], (pad, "stock module: graph replay vs eager")
+            assert r["kernels"]["first_tokens"] == r["kernels-graph"]["first_tokens"], (pad, "our kernels: plain launches vs graph replay")
+            # (a random 2-layer LLM over a 151936-token vocabulary has near-ties at bf16 resolution: the two IMPLEMENTATIONS are compared
+            # on logits, with a margin rule for the token, in tests/test_qwen2_prefill.py)
+            print(f"pad {pad}: first tokens kernels {r['kernels']['first_tokens']} stock {e['first_tokens']}; "
+                  f"prefill ms kernels {r['kernels']['prefill_first_token_ms']} graph {r['kernels-graph']['prefill_first_token_ms']} "
+                  f"hf-graph {g['prefill_first_token_ms']} hf-eager {e['prefill_first_token_ms']}")
     finally:
         ttft.QWEN2[896] = orig
-    assert g["prefill_mode"].startswith("hipGraph") and e["prefill_mode"] == "eager"
-    assert g["prompt_tokens"] == e["prompt_tokens"] == ttft.PROMPT_BEFORE + ttft.PROMPT_AFTER + 16
-    assert g["ttft_ms_median"] > 0 and e["ttft_ms_median"] > 0
 
     # same weights, same embeddings: graph replay and eager call agree on the first token
     torch.manual_seed(3)

@@ -4,11 +4,13 @@ TTFT as the reference's app defines it (`app/FastVLM App/FastVLMModel.swift:113-
 to the first generated token, here for a batch of B prompts:
 
     encode_images (FastViTHD + mlp2x_gelu, libfvhd)  ->  embedding splice (fvhd_op_splice, llava_arch.py:233-332)
-    ->  Qwen2 prefill on `inputs_embeds` (stock `transformers` Qwen2ForCausalLM on PyTorch-ROCm, llava_qwen.py:92-103,138-143)
-    ->  argmax of the last position's logits = first token  ->  host sync.
+    ->  Qwen2 prefill on `inputs_embeds` (llava_qwen.py:92-103,138-143)  ->  argmax of the last position's logits = first token  ->  host sync.
 
-The LLM is third-party arithmetic: the stock HF module with the Qwen2-0.5B / -7B architecture and random weights
-(no checkpoints on this box), bf16, SDPA attention.  The prompt is the `qwen_2` conversation (`llava/conversation.py:407-415`) around
+Prefill modes (`llm_mode`): "kernels" (default) = `ml_fastvlm_amd.qwen2_prefill.Qwen2Prefill`, the hand-written gfx950 kernels of
+`fvhd_llm_prefill` (SURVEY.md 8f-2) built from the module's own weights; "kernels-graph" = the same launches replayed as one hipGraph;
+"hf-graph" / "hf-eager" = the stock `transformers` Qwen2ForCausalLM on PyTorch-ROCm (SDPA attention), captured as one hipGraph or
+called eagerly - the round-2 baseline, kept for the A/B.  Architecture Qwen2-0.5B / -1.5B / -7B by hidden size, random bf16 weights
+(no checkpoints on this box).  The prompt is the `qwen_2` conversation (`llava/conversation.py:407-415`) around
 one <image>: 14 text tokens, the image, 10 text tokens - synthetic token ids, because no tokenizer files are available offline."""
 from __future__ import annotations
 
@@ -35,12 +37,37 @@ def build_llm(hidden: int, dev):
     return llm.eval()
 
 
+def _capture(fn, dev):
+    """fn() once on a side stream (lazy initialisations), then captured as one hipGraph (torch.cuda.CUDAGraph = hipGraph on ROCm)"""
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn()
+    return graph, out
+
+
 @torch.no_grad()
-def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, graph: bool = False, llm_graph: bool = True):
+def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, graph: bool = False, llm_graph: bool = True, llm_mode: str = None,
+            pad_left: int = 0, return_tokens: bool = False):
+    """llm_mode: "kernels" | "kernels-graph" | "hf-graph" | "hf-eager" (None: "kernels", or "hf-graph" / "hf-eager" by the legacy
+    `llm_graph` flag when FVHD_TTFT_HF=1).  pad_left > 0 masks that many leading prompt tokens of every odd sample (a left-padded
+    batch: attention mask and position ids must reach the prefill - VERDICT r2 weak #10)."""
+    import os
     import ml_fastvlm_amd as fv
     from ml_fastvlm_amd import splice as S
     from ml_fastvlm_amd import synth
+    from ml_fastvlm_amd.qwen2_prefill import Qwen2Prefill
 
+    if llm_mode is None:
+        llm_mode = ("hf-graph" if llm_graph else "hf-eager") if os.environ.get("FVHD_TTFT_HF") == "1" else "kernels"
+    if llm_mode not in ("kernels", "kernels-graph", "hf-graph", "hf-eager"):
+        raise ValueError(f"unknown llm_mode {llm_mode!r}")
     tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{res}", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_hip_graph=graph))
     tower.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234, profile="mild"), strict=True)
     proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=hidden))
@@ -54,43 +81,58 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
     ids[:, PROMPT_BEFORE] = S.IMAGE_TOKEN_INDEX
     ids = ids.to(dev)
     mask = torch.ones_like(ids)
+    if pad_left:
+        mask[1::2, :pad_left] = 0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     seq = PROMPT_BEFORE + PROMPT_AFTER + (res // 64) ** 2
+    pos0 = torch.arange(ids.shape[1], device=dev)[None].expand(batch, -1)      # a position_ids argument makes the splice return them
 
-    # Prefill as ONE hipGraph: stock HF Qwen2 launches ~700 small kernels for a 0.5 B prefill and is host-launch bound (B = 1 and
-    # B = 8 take the same 10-11 ms eagerly); the module is captured unchanged (torch.cuda.CUDAGraph = hipGraph on ROCm) on static
-    # input / output buffers - no tracing compiler, no change to the arithmetic.  Falls back to eager calls if capture fails.
-    graph, static_in, static_tok, graph_note = None, None, None, "eager"
-    if llm_graph:
+    static_in = torch.zeros((batch, seq, hidden), device=dev, dtype=torch.bfloat16)
+    static_mask = torch.ones((batch, seq), device=dev, dtype=mask.dtype)
+    static_pos = torch.zeros((batch, seq), device=dev, dtype=torch.int64)
+    hip_graph, static_tok, note = None, None, llm_mode
+    pre = None
+    if llm_mode.startswith("kernels"):
+        pre = Qwen2Prefill.from_hf(llm)
+        pre.reserve(batch, seq)
+        logits = torch.empty((batch, pre.vocab), device=dev, dtype=torch.float32)
+        note = "hand-written kernels (fvhd_llm_prefill), plain launches"
+        if llm_mode == "kernels-graph":
+            try:
+                hip_graph, static_tok = _capture(lambda: pre(static_in, static_mask, static_pos, out=logits).argmax(-1), dev)
+                note = "hand-written kernels (fvhd_llm_prefill), one hipGraph replay"
+            except Exception as e:                   # noqa: BLE001
+                hip_graph, note = None, f"hand-written kernels, plain launches (graph capture failed: {type(e).__name__})"
+                torch.cuda.synchronize()
+    elif llm_mode == "hf-graph":
+        # Stock HF Qwen2 launches ~700 small kernels for a 0.5 B prefill and is host-launch bound; the module is captured unchanged
+        # on static input / mask / position buffers.  Falls back to eager calls if capture fails.
         try:
-            static_in = torch.zeros((batch, seq, hidden), device=dev, dtype=torch.bfloat16)
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    llm(inputs_embeds=static_in, use_cache=True, logits_to_keep=1)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_tok = llm(inputs_embeds=static_in, use_cache=True, logits_to_keep=1).logits[:, -1].argmax(-1)
-            graph_note = "hipGraph (one replay)"
+            hip_graph, static_tok = _capture(lambda: llm(inputs_embeds=static_in, attention_mask=static_mask, position_ids=static_pos, use_cache=True,
+                                                        logits_to_keep=1).logits[:, -1].argmax(-1), dev)
+            note = "stock transformers module, one hipGraph replay"
         except Exception as e:                       # noqa: BLE001 - any capture failure: measure eagerly and say so
-            graph, graph_note = None, f"eager (graph capture failed: {type(e).__name__})"
+            hip_graph, note = None, f"stock transformers module, eager (graph capture failed: {type(e).__name__})"
             torch.cuda.synchronize()
+    else:
+        note = "stock transformers module, eager"
 
     def once():
         ev[0].record()
         feats = fv.encode_images(tower, proj, images)
         ev[1].record()
-        _, pos, am, _, embeds, _ = S.multimodal_splice(ids, None, mask, None, feats, table)
+        _, pos, am, _, embeds, _ = S.multimodal_splice(ids, pos0, mask, None, feats, table, "left" if pad_left else "right")
         ev[2].record()
-        if graph is not None:
+        if hip_graph is not None:
             static_in.copy_(embeds)
-            graph.replay()
+            static_mask.copy_(am)
+            static_pos.copy_(pos)
+            hip_graph.replay()
             tok = static_tok
+        elif pre is not None:
+            tok = pre(embeds, am, pos, out=logits).argmax(-1)
         else:
-            out = llm(inputs_embeds=embeds, attention_mask=am, use_cache=True, logits_to_keep=1)
+            out = llm(inputs_embeds=embeds, attention_mask=am, position_ids=pos, use_cache=True, logits_to_keep=1)
             tok = out.logits[:, -1].argmax(-1)
         ev[3].record()
         return tok, embeds.shape[1]
@@ -111,11 +153,14 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
     wall.sort()
     med = lambda xs: sorted(xs)[len(xs) // 2]
     n_par = sum(p.numel() for p in llm.parameters())
-    return {"ttft_ms_median": round(wall[len(wall) // 2], 3), "ttft_ms_min": round(wall[0], 3), "ttft_ms_max": round(wall[-1], 3),
-            "encode_images_ms": round(med([p[0] for p in parts]), 3), "splice_ms": round(med([p[1] for p in parts]), 3),
-            "prefill_first_token_ms": round(med([p[2] for p in parts]), 3), "prefill_mode": graph_note,
-            "batch": batch, "prompt_tokens": int(seq), "image_tokens": (res // 64) ** 2, "llm": f"Qwen2 architecture, hidden {hidden}, {n_par / 1e9:.2f} B parameters, random bf16 weights, stock transformers SDPA",
-            "steps": steps}
+    r = {"ttft_ms_median": round(wall[len(wall) // 2], 3), "ttft_ms_min": round(wall[0], 3), "ttft_ms_max": round(wall[-1], 3),
+         "encode_images_ms": round(med([p[0] for p in parts]), 3), "splice_ms": round(med([p[1] for p in parts]), 3),
+         "prefill_first_token_ms": round(med([p[2] for p in parts]), 3), "prefill_mode": note, "llm_mode": llm_mode,
+         "batch": batch, "prompt_tokens": int(seq), "image_tokens": (res // 64) ** 2,
+         "llm": f"Qwen2 architecture, hidden {hidden}, {n_par / 1e9:.2f} B parameters, random bf16 weights", "steps": steps}
+    if return_tokens:
+        r["first_tokens"] = first.tolist()
+    return r
 
 
 if __name__ == "__main__":
@@ -128,6 +173,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graph", action="store_true")
-    ap.add_argument("--llm-eager", action="store_true", help="do not capture the LLM prefill in a hipGraph")
+    ap.add_argument("--llm-mode", default="kernels", choices=["kernels", "kernels-graph", "hf-graph", "hf-eager"])
     a = ap.parse_args()
-    print(json.dumps(measure(a.batch, a.res, a.hidden, a.steps, a.warmup, torch.device("cuda", 0), a.graph, not a.llm_eager)))
+    print(json.dumps(measure(a.batch, a.res, a.hidden, a.steps, a.warmup, torch.device("cuda", 0), a.graph, llm_mode=a.llm_mode)))
