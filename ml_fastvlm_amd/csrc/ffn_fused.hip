@@ -45,35 +45,29 @@ __host__ __device__ __forceinline__ int w2_off(int row, int slot)               
     return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
 }
 
-// erf GELU (fvhd_common.h: Phi(x) = 0.5 + xc Q(xc^2), degree-7 Q) on PAIRS of hidden values: every step is one v_pk_*_f32,
-// so a pair costs 10 packed + 2 v_med3 issue slots (6 per value; + one packed add where the bias is not already in the
-// accumulator).  Cut into six half-stages of 2-3 instructions; the software pipeline below advances one pair by one
+// erf GELU (fvhd_common.h: Phi(x) = 0.5 + xc Q(xc^2); degree-5 Q on clamp(x, +-3.5) in this kernel, see FVHD_GELU5_*) on PAIRS of
+// hidden values: every step is one v_pk_*_f32, so a pair costs 8 packed + 2 v_med3 issue slots (5 per value; + one packed add where
+// the bias is not already in the accumulator).  Cut into six half-stages of 2-3 instructions; the software pipeline below advances one pair by one
 // half-stage per unit.
 struct GeluSt { f32x2 x, xc, u, q; };
 #define FFN_PK(c) (f32x2{c, c})
+#ifndef FVHD_FFN_GELU_DEG
+#define FVHD_FFN_GELU_DEG 5          // 7 = the degree-7 fit every other kernel uses (A/B builds: -DFVHD_FFN_GELU_DEG=7)
+#endif
 template <int H> FVHD_DEV void gelu_half(GeluSt& g, f32x2 x, f32x2& out)
 {
+#if FVHD_FFN_GELU_DEG == 7
     if constexpr (H == 0) {
         g.x = x;
         g.xc = f32x2{__builtin_amdgcn_fmed3f(x[0], -FVHD_GELU_CLAMP, FVHD_GELU_CLAMP), __builtin_amdgcn_fmed3f(x[1], -FVHD_GELU_CLAMP, FVHD_GELU_CLAMP)};
     } else if constexpr (H == 1) {
         g.u = g.xc * g.xc;
-#if FVHD_GELU_DEG == 7
         g.q = __builtin_elementwise_fma(FFN_PK(FVHD_GELU_C7), g.u, FFN_PK(FVHD_GELU_C6));
-#else
-        g.q = __builtin_elementwise_fma(FFN_PK(FVHD_GELU_C5), g.u, FFN_PK(FVHD_GELU_C4));
-#endif
     } else if constexpr (H == 2) {
-#if FVHD_GELU_DEG == 7
         g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C5));
         g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C4));
-#else
-        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C3));
-#endif
     } else if constexpr (H == 3) {
-#if FVHD_GELU_DEG == 7
         g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C3));
-#endif
         g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C2));
     } else if constexpr (H == 4) {
         g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU_C1));
@@ -81,6 +75,24 @@ template <int H> FVHD_DEV void gelu_half(GeluSt& g, f32x2 x, f32x2& out)
     } else {
         out = g.x * __builtin_elementwise_fma(g.xc, g.q, FFN_PK(0.5f));
     }
+#else
+    if constexpr (H == 0) {
+        g.x = x;
+        g.xc = f32x2{__builtin_amdgcn_fmed3f(x[0], -FVHD_GELU5_CLAMP, FVHD_GELU5_CLAMP), __builtin_amdgcn_fmed3f(x[1], -FVHD_GELU5_CLAMP, FVHD_GELU5_CLAMP)};
+    } else if constexpr (H == 1) {
+        g.u = g.xc * g.xc;
+        g.q = __builtin_elementwise_fma(FFN_PK(FVHD_GELU5_C5), g.u, FFN_PK(FVHD_GELU5_C4));
+    } else if constexpr (H == 2) {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU5_C3));
+    } else if constexpr (H == 3) {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU5_C2));
+    } else if constexpr (H == 4) {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU5_C1));
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_PK(FVHD_GELU5_C0));
+    } else {
+        out = g.x * __builtin_elementwise_fma(g.xc, g.q, FFN_PK(0.5f));
+    }
+#endif
 }
 
 // 16 B/lane LDS-DMA (global -> LDS, no VGPR staging): LDS destination = wave-uniform byte address `lds_dst` + lane*16.
