@@ -255,6 +255,11 @@ int fvhd_op_rmsnorm(fvhd_stream_t stream, const void* x, void* y, const float* w
  * for ONE layer ([M / T][n_kv_heads][T][head_dim]) or NULL */
 int fvhd_op_rope(fvhd_stream_t stream, void* qkv, const int64_t* pos, const float* table, void* k_cache, void* v_cache, int M, int T,
                  int n_heads, int n_kv_heads, int head_dim, int table_positions);
+/* out = resid + A . Wt^T with K split over `splits` workgroups per output tile (Qwen2 down_proj at prefill: few tiles, long K):
+ * A [M, K], Wt [N, K], resid [M, N] or NULL (may alias out), out [M, N] bf16; partial: fp32 scratch [splits][M][N]; the slices are
+ * summed in order (deterministic) and rounded once.  N % 128 == 0, K % (64 * splits) == 0. */
+int fvhd_op_gemm_splitk(fvhd_stream_t stream, const void* A, const void* Wt, const void* resid, void* out, float* partial, int M, int N,
+                        int K, int splits);
 /* causal grouped-query attention with a key-padding mask: qkv [B*T, (n_heads + 2 n_kv_heads) * head_dim] bf16 ->
  * out [B*T, n_heads * head_dim] bf16; key_valid uint8 [B, T] or NULL; head_dim in {64, 128} */
 int fvhd_op_attention_causal(fvhd_stream_t stream, const void* qkv, void* out, const uint8_t* key_valid, int B, int T, int n_heads,

@@ -71,6 +71,7 @@ def _declare(lib) -> None:
         "fvhd_op_rmsnorm": (ci, [vp, vp, vp, vp, ci, ci, cf]),
         "fvhd_op_rope": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci]),
         "fvhd_op_attention_causal": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci]),
+        "fvhd_op_gemm_splitk": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci]),
     }
     del fp, cl
     for name, (res, args) in sig.items():

@@ -83,9 +83,14 @@ FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias
 template <int NF, int BK, int EPI, int ODT>
 __global__ __launch_bounds__(256) void gemm_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
-    const float* __restrict__ ls, const bf16* resid, void* out, int M, int N, int K, int tiles_n, int nwg)
+    const float* __restrict__ ls, const bf16* resid, void* out_, int M, int N, int K, int tiles_n, int nwg, int ldk)
 {
+    // K = the K range one workgroup reduces; ldk = row stride of A and Wt.  Plain launches: ldk == K, gridDim.y == 1.  Split-K launches
+    // (fvhd_launch_gemm_splitk): blockIdx.y = slice, A / Wt advance by slice * K columns, out = the slice's fp32 partial [M, N].
     constexpr int BM = 128, BN = 32 * NF, MF = 4;
+    A += (size_t)blockIdx.y * K;
+    Wt += (size_t)blockIdx.y * K;
+    void* out = ODT == FVHD_F32 ? (void*)((float*)out_ + (size_t)blockIdx.y * M * N) : out_;
     constexpr int ROWB = BK * 2;
     constexpr int CPR = BK / 8;                       // 16-B chunks per tile row
     constexpr int A_CH = BM * CPR / 256;
@@ -118,14 +123,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(
     for (int i = 0; i < A_CH; ++i) {
         const int idx = i * 256 + tid, row = idx / CPR, ks = idx % CPR;
         const int gr = min(m0 + row, M - 1);
-        a_src[i] = A + (size_t)gr * K + ks * 8;
+        a_src[i] = A + (size_t)gr * ldk + ks * 8;
         a_dst[i] = lds_off<BK>(row, ks);
     }
 #pragma unroll
     for (int i = 0; i < W_CH; ++i) {
         const int idx = i * 256 + tid, row = min(idx / CPR, BN - 1), ks = idx % CPR;
         const int gr = min(n0 + row, N - 1);
-        w_src[i] = Wt + (size_t)gr * K + ks * 8;
+        w_src[i] = Wt + (size_t)gr * ldk + ks * 8;
         w_dst[i] = (idx < BN * CPR) ? lds_off<BK>(row, ks) : -1;
     }
 
@@ -183,7 +188,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // fragments): LDS-DMA writes lane-linearly, so the swizzle is applied on the GLOBAL side - lane l of a 1-KiB piece (8 rows x
 // 128 B) fetches the 16-B chunk ks = (l & 7) ^ ((row >> 1) & 7) of row (l >> 3): still 8 whole 128-B lines per instruction.
 // Each wave issues 4 of the 32 A pieces and 2 of the 16 W pieces of a K tile.  Taken when M % 256 == 0, N % 128 == 0, K % 64 == 0.
-constexpr int G2_RS = 3, G2_STAGE = (256 + 128) * 128;
+// v3 (round 3): the same streaming kernel with a 256 x 256 tile - 8 waves as 2 (M) x 4 (N), 128 x 64 per wave: 12 fragment reads per 32
+// MFMAs instead of 8 per 16 (the LDS pipe was the co-bottleneck of v2), 128 accumulator registers per lane, two 64-KB stages (128 KB:
+// one workgroup per CU, two waves per SIMD) - the "256^2 tile, glds, 2 LDS buffers, BK = 64, vmcnt(0) + barrier" structure of
+// cdna_hip_programming.md 5.  Taken when N % 256 == 0 and there are at least two rounds of tiles.
+template <int BN> struct G2Cfg {
+    static constexpr int RS = BN == 256 ? 2 : 3, STAGE = (256 + BN) * 128, LDS = RS * STAGE;
+};
 
 FVHD_DEV void glds_piece(unsigned voff, const void* sbase, unsigned m0v)
 {
@@ -192,20 +203,22 @@ FVHD_DEV void glds_piece(unsigned voff, const void* sbase, unsigned m0v)
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0v) : "memory");
 }
 
-template <int EPI, int ODT, int NWV>
+template <int EPI, int ODT, int NWV, int BN = 128>
 __global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ ls, const bf16* resid, void* out, int M, int N, int K, int tiles_n, int nwg)
 {
-    // NWV = 8: waves 4 (M) x 2 (N), 64 x 64 each (two per SIMD).  NWV = 4: 2 x 2, 128 x 64 each - 12 instead of 16 fragment reads per 32 MFMAs
-    // (the LDS pipe is the co-bottleneck: 8 ds_read_b128 per 16 MFMAs keep it ~75 % busy), one wave per SIMD.
-    constexpr int BM = 256, BN = 128, BK = 64, MF = 32 / NWV, NF = 4, RS = G2_RS, PA = 32 / NWV, PW = 16 / NWV;
+    // BN = 128, NWV = 8: waves 4 (M) x 2 (N), 64 x 64 each (two per SIMD).  BN = 128, NWV = 4: 2 x 2, 128 x 64 each - 12 instead of 16 fragment
+    // reads per 32 MFMAs, one wave per SIMD.  BN = 256, NWV = 8: 2 x 4, 128 x 64 each, two per SIMD.
+    constexpr int BM = 256, BK = 64, WN = BN / 64, WM = NWV / WN, MF = BM / WM / 16, NF = 4, RS = G2Cfg<BN>::RS, STAGE = G2Cfg<BN>::STAGE;
+    constexpr int PA = 32 / NWV, PW = (BN / 8) / NWV;         // 1-KiB pieces (8 rows x 128 B) of the A / W tile per wave
+    static_assert(WM * WN == NWV && MF * 16 * WM == BM, "wave grid");
     extern __shared__ __attribute__((aligned(16))) char lds2[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, g = lane >> 4;
     const int L = xcd_remap(blockIdx.x, nwg);               // same super-tile order as v1 (8 x 8 tiles share their panels in one XCD's L2)
-    constexpr int GN = 8;
+    constexpr int GN = BN == 256 ? 4 : 8;
     const int tiles_m = nwg / tiles_n;
     const int grp = L / (tiles_m * GN), rem = L - grp * tiles_m * GN;
     const int wg = min(GN, tiles_n - grp * GN);
@@ -226,12 +239,12 @@ __global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
     const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * 8 * PW) * K);  // W pieces PW wave ..
     const unsigned lds0 = lds_addr(lds2);
     auto issue = [&](int kt) {
-        const unsigned st = lds0 + (kt % RS) * G2_STAGE;
+        const unsigned st = lds0 + (kt % RS) * STAGE;
         const size_t ko = (size_t)kt * BK * 2;
 #pragma unroll
-        for (int j = 0; j < PA; ++j) glds_piece(va[j & 1], abase + (size_t)j * 8 * K * 2 + ko, st + (wave * PA + j) * 1024);
+        for (int j = 0; j < PA; ++j) glds_piece(va[(wave * PA + j) & 1], abase + (size_t)j * 8 * K * 2 + ko, st + (wave * PA + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < PW; ++j) glds_piece(vw[j & 1], wbase + (size_t)j * 8 * K * 2 + ko, st + 256 * 128 + (wave * PW + j) * 1024);
+        for (int j = 0; j < PW; ++j) glds_piece(vw[(wave * PW + j) & 1], wbase + (size_t)j * 8 * K * 2 + ko, st + 256 * 128 + (wave * PW + j) * 1024);
     };
 
     f32x4 acc[MF][NF];
@@ -245,12 +258,12 @@ __global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
     for (int i = 0; i < RS - 1; ++i)
         if (i < nk) issue(i);
     for (int kt = 0; kt < nk; ++kt) {
-        // own pieces of tile kt have landed when at most the one later tile's PA + PW are outstanding (loads only in this loop)
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PW) : "memory");
+        // own pieces of tile kt have landed when at most the RS - 2 later tiles' PA + PW are outstanding (loads only in this loop)
+        if (RS > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RS - 2) * (PA + PW)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                              // tile kt visible to every wave; tile kt - 1 fully consumed
         if (kt + RS - 1 < nk) issue(kt + RS - 1);     // into the stage tile kt - 1 occupied
-        const char* ldsA = lds2 + (kt % RS) * G2_STAGE;
+        const char* ldsA = lds2 + (kt % RS) * STAGE;
         const char* ldsW = ldsA + 256 * 128;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -277,7 +290,7 @@ extern "C" void fvhd_debug_set_gemm_v2(int on) { g_gemm_v2 = on; }
 static constexpr int g_gemm_v2 = 1;
 #endif
 
-template <int EPI, int ODT, int NWV>
+template <int EPI, int ODT, int NWV, int BN = 128>
 static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
                                  const bf16* resid, void* out, int M, int N, int K)
 {
@@ -285,13 +298,28 @@ static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_RS * G2_STAGE);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<BN>::LDS);
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = true;
     }
-    const int tiles_m = M / 256, tiles_n = N / 128, nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV>), dim3(nwg), dim3(64 * NWV), G2_RS * G2_STAGE, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+    const int tiles_m = M / 256, tiles_n = N / BN, nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN>), dim3(nwg), dim3(64 * NWV), G2Cfg<BN>::LDS, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
     return hipGetLastError();
+}
+
+template <int BN>
+static hipError_t dispatch_gemm256(hipStream_t st, const bf16* a, const bf16* w, const float* bias, const float* ls, const bf16* r, void* out,
+                                   int M, int N, int K, int epi)
+{
+    switch (epi) {
+    case EPI_NONE: return launch_gemm256<EPI_NONE, FVHD_BF16, 8, BN>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS: return launch_gemm256<EPI_BIAS, FVHD_BF16, 8, BN>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_GELU: return launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8, BN>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_LS_RESID: return launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 8, BN>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_RESID: return launch_gemm256<EPI_RESID, FVHD_BF16, 8, BN>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_SWIGLU: return launch_gemm256<EPI_SWIGLU, FVHD_BF16, 8, BN>(st, a, w, bias, ls, r, out, M, N, K);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int NF, int BK, int EPI, int ODT>
@@ -302,8 +330,37 @@ static hipError_t launch_gemm(hipStream_t st, const bf16* A, const bf16* Wt, con
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm_kernel<NF, BK, EPI, ODT>), dim3(nwg), dim3(256), 0, st,
-                       A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+                       A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg, K);
     return hipGetLastError();
+}
+
+// ---- split-K: out = resid + A . Wt^T for SMALL M x N with a LONG K (Qwen2 down_proj at prefill: 2304 x 896 x 4864 = 126 tiles of
+// 76 serial K steps on 256 CUs).  `splits` slices of K run as independent workgroups of the v1 kernel writing fp32 partials
+// [splits][M][N]; a second kernel sums them in slice order (deterministic), adds the residual and rounds once to bf16.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const bf16* resid, bf16* out, long mn, int splits)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= mn) return;
+    f32x4 v = *(const f32x4*)(part + i);
+    for (int s = 1; s < splits; ++s) v += *(const f32x4*)(part + (size_t)s * mn + i);
+    if (resid) v += bf4_to_f32(*(const bf16x4*)(resid + i));
+    *(bf16x4*)(out + i) = f32_to_bf4(v);
+}
+
+// A [M, K] bf16, Wt [N, K] bf16, resid bf16 [M, N] or null (may alias out), out [M, N] bf16, partial: fp32 scratch [splits][M][N].
+// K % (64 * splits) == 0, N % 128 == 0.
+extern "C" int fvhd_launch_gemm_splitk(hipStream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial,
+                                       int M, int N, int K, int splits)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || N % 128 || K % (64 * splits) || !partial) return (int)hipErrorInvalidValue;
+    const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
+    hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
+                       nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const long mn = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, partial, (const bf16*)resid, (bf16*)out, mn, splits);
+    return (int)hipGetLastError();
 }
 
 template <int NF, int BK>
@@ -342,15 +399,13 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     // (tools/bench_ops.py gemm, profiles/r02_gemm_v1_v2.log) fc1 272 -> 264 us, fc2 (K = 3072) 215 -> 196, stage-5 qkv 177 -> 155,
     // projector fc 68 -> 56; with 384 tiles (stage-5 proj / fc2, 1.5 rounds) v1 stays ahead.  A 4-wave variant with 128 x 64 per
     // wave (fewer fragment reads, one wave per SIMD) was 10-25 % slower: nothing covers the LDS read latency.
-    if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128 && (long long)(M / 256) * (N / 128) >= 512) {
-        switch (epi) {
-        case EPI_NONE: return (int)launch_gemm256<EPI_NONE, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
-        case EPI_BIAS: return (int)launch_gemm256<EPI_BIAS, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
-        case EPI_BIAS_GELU: return (int)launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
-        case EPI_BIAS_LS_RESID: return (int)launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
-        case EPI_RESID: return (int)launch_gemm256<EPI_RESID, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
-        case EPI_SWIGLU: return (int)launch_gemm256<EPI_SWIGLU, FVHD_BF16, 8>(st, a, w, bias, ls, r, out, M, N, K);
-        }
+    // g_gemm_v2 (debug build): 0 = v1 only, 1 = the rule below, 2 = the 256 x 128 tile wherever it is legal, 3 = the 256 x 256 tile wherever legal
+    if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128) {
+        const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
+        const bool use256 = g_gemm_v2 == 3 && t256 > 0;        // (not in the default rule until measured: tools/bench_ops.py gemm)
+        const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && t128 >= 512);
+        if (use256) return (int)dispatch_gemm256<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
+        if (use128) return (int)dispatch_gemm256<128>(st, a, w, bias, ls, r, out, M, N, K, epi);
     }
     const bool nf3 = (N % 128 != 0) && (N % 96 == 0);
     const bool bk64 = (K % 64 == 0);

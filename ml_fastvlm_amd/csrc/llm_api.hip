@@ -14,6 +14,7 @@
 
 extern "C" {
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
+int fvhd_launch_gemm_splitk(hipStream_t, const void*, const void*, const void*, void*, float*, int, int, int, int);
 int fvhd_launch_rmsnorm(hipStream_t, const void*, void*, const float*, int, int, float);
 int fvhd_launch_rope(hipStream_t, void*, const long*, const float*, void*, void*, int, int, int, int, int, int);
 int fvhd_launch_llm_attention(hipStream_t, const void*, void*, const unsigned char*, int, int, int, int, int);
@@ -25,6 +26,7 @@ int fvhd_set_error(const char* msg);     // fvhd_api.hip: the library's one thre
 namespace {
 
 constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_RESID = 4, EPI_SWIGLU = 5;
+constexpr int kMaxSplits = 4;
 
 int lfail(const std::string& m) { return fvhd_set_error(m.c_str()); }
 int lhip(const char* what, hipError_t e) { return lfail(std::string(what) + ": " + hipGetErrorString(e)); }
@@ -86,7 +88,8 @@ struct fvhd_llm {
     size_t ws_bytes = 0;
     int ws_rows = 0, ws_batch = 0, ws_pos = 0;
     char *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *last = nullptr, *lastn = nullptr;
-    float* rope = nullptr;
+    float *rope = nullptr, *part = nullptr;
+    int down_splits = 1;
 };
 
 namespace {
@@ -146,7 +149,8 @@ int ensure_ws(fvhd_llm* c, int B, int T, hipStream_t st, bool check_capture)
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     const size_t o_h = take((size_t)nrows * c->H * 2), o_xn = take((size_t)nrows * c->H * 2), o_qkv = take((size_t)nrows * c->qkvw * 2),
                  o_att = take((size_t)nrows * c->nh * c->hd * 2), o_act = take((size_t)nrows * c->I * 2), o_last = take((size_t)lb * c->H * 2),
-                 o_lastn = take((size_t)lb * c->H * 2), o_rope = take((size_t)np * c->hd * 4);
+                 o_lastn = take((size_t)lb * c->H * 2), o_rope = take((size_t)np * c->hd * 4),
+                 o_part = take((size_t)kMaxSplits * nrows * c->H * 4);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return lhip("hipDeviceSynchronize", e);
     if (c->ws) (void)hipFree(c->ws);
@@ -157,7 +161,7 @@ int ensure_ws(fvhd_llm* c, int B, int T, hipStream_t st, bool check_capture)
     if (e != hipSuccess) return lhip("hipMemset(llm workspace)", e);
     c->ws_bytes = off; c->ws_rows = nrows; c->ws_batch = nb; c->ws_pos = np;
     c->h = c->ws + o_h; c->xn = c->ws + o_xn; c->qkv = c->ws + o_qkv; c->att = c->ws + o_att; c->act = c->ws + o_act;
-    c->last = c->ws + o_last; c->lastn = c->ws + o_lastn; c->rope = (float*)(c->ws + o_rope);
+    c->last = c->ws + o_last; c->lastn = c->ws + o_lastn; c->rope = (float*)(c->ws + o_rope); c->part = (float*)(c->ws + o_part);
     // rotary table, fp32 like Qwen2RotaryEmbedding.forward: inv_freq_i = theta^(-2i/hd), angle = pos * inv_freq_i, (cos, sin)
     std::vector<float> tab((size_t)np * c->hd);
     for (int p = 0; p < np; ++p)
@@ -199,6 +203,7 @@ int fvhd_llm_create(fvhd_llm** out, int device, int hidden, int n_layers, int n_
     fvhd_llm* c = new fvhd_llm();
     c->device = device; c->H = hidden; c->L = n_layers; c->nh = n_heads; c->nkv = n_kv_heads; c->hd = head_dim; c->I = intermediate; c->V = vocab;
     c->eps = rms_eps; c->theta = rope_theta; c->qkvw = qkvw;
+    if (const char* ev = getenv("FVHD_LLM_SPLITK")) c->down_splits = atoi(ev);      // 0 = never split (A/B)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     c->lo.resize(n_layers);
@@ -325,7 +330,16 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
         LCHECK(fvhd_launch_gemm(st, c->att, w + o.wo, nullptr, nullptr, c->h, c->h, Mp, H, nh * hd, EPI_RESID, FVHD_BF16), "o_proj gemm");
         LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln2), Mp, H, c->eps), "rmsnorm 2");
         LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wgu, nullptr, nullptr, nullptr, c->act, Mp, 2 * I, H, EPI_SWIGLU, FVHD_BF16), "gate_up gemm");
-        LCHECK(fvhd_launch_gemm(st, c->act, w + o.wd, nullptr, nullptr, c->h, c->h, Mp, H, I, EPI_RESID, FVHD_BF16), "down gemm");
+        // down_proj: few output tiles (Mp / 128 x H / 128), long K = I.  While the tiles of one slice do not fill the chip twice over,
+        // K is split across workgroups (fp32 partials + a deterministic reduce that also adds the residual): 70 -> ~25 us per layer at
+        // the 0.5 B prefill shape (B = 8 x 285 tokens)
+        const long tiles = (long)(Mp / 128) * (H / 128);
+        int splits = 1;
+        if (c->down_splits > 0 && H % 128 == 0)
+            for (int sp = kMaxSplits; sp > 1; sp >>= 1)
+                if (tiles * sp <= 512 && I % (64 * sp) == 0) { splits = sp; break; }
+        if (splits > 1) LCHECK(fvhd_launch_gemm_splitk(st, c->act, w + o.wd, c->h, c->h, c->part, Mp, H, I, splits), "down gemm (split-K)");
+        else LCHECK(fvhd_launch_gemm(st, c->act, w + o.wd, nullptr, nullptr, c->h, c->h, Mp, H, I, EPI_RESID, FVHD_BF16), "down gemm");
     }
     // logits of the LAST position of every sequence (what generate() reads: outputs.logits[:, -1, :])
     LCHECK(fvhd_launch_gather_rows(st, c->h, c->last, B, T, T - 1, H), "gather last rows");
@@ -357,6 +371,14 @@ int fvhd_op_rope(fvhd_stream_t st, void* qkv, const int64_t* pos, const float* t
     if (!qkv || !table) return lfail("fvhd_op_rope: NULL pointer");
     int e = fvhd_launch_rope((hipStream_t)st, qkv, (const long*)pos, table, k_cache, v_cache, M, T, n_heads, n_kv_heads, head_dim, table_positions);
     return e ? lhip("fvhd_op_rope", (hipError_t)e) : 0;
+}
+
+int fvhd_op_gemm_splitk(fvhd_stream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial, int M, int N, int K, int splits)
+{
+    if (!A || !Wt || !out || !partial) return lfail("fvhd_op_gemm_splitk: NULL pointer");
+    if (splits < 1 || N % 128 || K % (64 * splits)) return lfail("fvhd_op_gemm_splitk: needs N % 128 == 0 and K % (64 * splits) == 0");
+    int e = fvhd_launch_gemm_splitk((hipStream_t)st, A, Wt, resid, out, partial, M, N, K, splits);
+    return e ? lhip("fvhd_op_gemm_splitk", (hipError_t)e) : 0;
 }
 
 int fvhd_op_attention_causal(fvhd_stream_t st, const void* qkv, void* out, const uint8_t* key_valid, int B, int T, int n_heads, int n_kv_heads, int head_dim)

@@ -203,7 +203,7 @@ def test_causal_gqa_attention(hd, nh, nkv, B, T, pad):
     got = od.float().cpu().view(B, T, nh * hd)
     valid = mask.bool()
     assert torch.isfinite(got).all()
-    _close(got[valid], want[valid], f"attention hd{hd} T{T} {pad}", rtol=2e-2, atol_rms=1e-2)      # P is rounded to bf16 for the PV MFMA
+    _close(got[valid], want[valid], f"attention hd{hd} T{T} {pad}", rtol=2e-2, atol_rms=2e-2)      # P is rounded to bf16 for the PV MFMA (the tolerance of the tower's attention test)
 
 
 @pytest.mark.gpu
@@ -227,6 +227,15 @@ def test_gemm_swiglu_and_residual_epilogues():
                                     M, K, I, _lib.EPI_RESID, _lib.BF16), "resid")
         torch.cuda.synchronize()
         _close(rd, res + act @ Wd.t(), f"resid {M}x{I}x{K}")
+    # split-K (down_proj at the prefill shape): partial sums in slice order + residual, one rounding
+    for M, N, K, splits in ((2304, 896, 4864, 4), (300, 128, 512, 2), (256, 256, 256, 1)):
+        A, W, res = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5), _bf(torch.randn(M, N, generator=g))
+        rd = res.to(DEV, torch.bfloat16)
+        part = torch.empty(splits * M * N, device=DEV, dtype=torch.float32)
+        _lib.check(lib.fvhd_op_gemm_splitk(_stream(), _p(A.to(DEV, torch.bfloat16)), _p(W.to(DEV, torch.bfloat16)), _p(rd), _p(rd), _p(part), M, N, K, splits),
+                   "splitk")
+        torch.cuda.synchronize()
+        _close(rd, res + A @ W.t(), f"split-K {M}x{N}x{K}/{splits}")
     # fp32 logits without bias (lm_head), few rows
     A = _bf(torch.randn(8, 896, generator=g))
     W = _bf(torch.randn(1024, 896, generator=g) * 896 ** -0.5)

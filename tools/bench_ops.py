@@ -166,18 +166,34 @@ def bench_gemm(B=32):
               ("s3 fc2", B * 1024, 768, 3072, 3), ("s4 qkv", B * 256, 4608, 1536, 0), ("s4 proj", B * 256, 1536, 1536, 3),
               ("s4 fc1", B * 256, 6144, 1536, 2), ("s4 fc2", B * 256, 1536, 6144, 3),
               ("proj0 H896", B * 256, 896, 3072, 2), ("proj2 H896", B * 256, 896, 896, 1),
-              ("proj0 H3584", B * 256, 3584, 3072, 2), ("proj2 H3584", B * 256, 3584, 3584, 1)]
+              ("proj0 H3584", B * 256, 3584, 3072, 2), ("proj2 H3584", B * 256, 3584, 3584, 1),
+              # Qwen2-0.5B prefill at B = 8 x 285 tokens (padded to 2304 rows): qkv, o_proj, gate|up (SwiGLU epilogue), down
+              ("llm qkv", 2304, 1152, 896, 1), ("llm o_proj", 2304, 896, 896, 4), ("llm gate_up", 2304, 9728, 896, 5), ("llm down", 2304, 896, 4864, 4)]
     raw = _knobs()
-    for v2 in (0, 1):
+    for v2 in (0, 2, 3, 1):
       raw.fvhd_debug_set_gemm_v2(v2)
-      print(f"--- gemm: {('v1 only (128x128, register prefetch)', 'default dispatch (256x128 LDS-DMA ring where it pays)')[v2]}")
+      print(f"--- gemm: {('v1 only (128x128, register prefetch)', 'default dispatch', '256x128 LDS-DMA ring wherever legal', '256x256 tile / 2-stage LDS-DMA wherever legal')[v2]}")
       for name, M, N, K, epi in shapes:
         A = torch.randn(M, K).to(DEV, torch.bfloat16)
         W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
         bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
-        out = torch.randn(M, N).to(DEV, torch.bfloat16)
+        out = torch.randn(M, N).to(DEV, torch.bfloat16)      # (SwiGLU writes the first M * N / 2 elements of it)
         t = timeit(lambda: _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(out), p(out), M, N, K, epi, 2)))
         print(f"gemm {name:12s} M={M:8d} N={N:5d} K={K:5d} epi={epi}: {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+    for name, M, N, K, epi in [("check fc1-like", 1024, 3072, 768, 2), ("check fc2-like", 1024, 768, 3072, 3), ("check swiglu", 512, 1024, 256, 5)]:
+        A = torch.randn(M, K).to(DEV, torch.bfloat16)
+        W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
+        bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
+        res = torch.randn(M, N).to(DEV, torch.bfloat16)
+        outs = []
+        for v2 in (0, 2, 3):
+            raw.fvhd_debug_set_gemm_v2(v2)
+            out = res.clone() if epi != 5 else torch.zeros(M, N // 2, device=DEV, dtype=torch.bfloat16)
+            _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(res), p(out), M, N, K, epi, 2))
+            torch.cuda.synchronize()
+            outs.append(out.float())
+        print(f"gemm {name}: v1 vs 256x128 equal {bool(torch.equal(outs[0], outs[1]))}, v1 vs 256x256 equal {bool(torch.equal(outs[0], outs[2]))}, "
+              f"max diff {float((outs[0] - outs[2]).abs().max()):.3g}")
     raw.fvhd_debug_set_gemm_v2(1)
 
 
