@@ -402,7 +402,11 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     // g_gemm_v2 (debug build): 0 = v1 only, 1 = the rule below, 2 = the 256 x 128 tile wherever it is legal, 3 = the 256 x 256 tile wherever legal
     if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128) {
         const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
-        const bool use256 = g_gemm_v2 == 3 && t256 > 0;        // (not in the default rule until measured: tools/bench_ops.py gemm)
+        // measured (tools/bench_ops.py gemm, profiles/r03_gemm_tiles.log, B = 32): the 256 x 256 tile wins from N = 2304 on when it has
+        // ~2 rounds of tiles - stage-3 qkv 186 -> 165 us, fc1 268 -> 242, stage-4 fc1 224 -> 204, 7B projector 239 / 267 -> 211 / 239 -
+        // ties or loses below (N = 768: 64 -> 74 us) and with 1.3 rounds (prefill gate|up, 342 tiles: 59 -> 65).  All three kernels
+        // produce identical bits (same K order per output element).
+        const bool use256 = g_gemm_v2 == 3 ? t256 > 0 : (g_gemm_v2 == 1 && N >= 2304 && t256 >= 448);
         const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && t128 >= 512);
         if (use256) return (int)dispatch_gemm256<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
         if (use128) return (int)dispatch_gemm256<128>(st, a, w, bias, ls, r, out, M, N, K, epi);

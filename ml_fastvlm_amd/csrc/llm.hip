@@ -237,9 +237,14 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[w], mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[w] - m_new) * scale_log2e);
+            // a row that has seen no visible key yet (a padding query in front of a left-padded sequence, or the leading all-padding
+            // tiles of a real one) keeps m = -1e30; its exponent is taken against 0 instead, so every masked score gives exp2(-huge)
+            // = 0 exactly - with the -1e30 reference the difference of two rounded 1.8e29 products is +-1e22, i.e. exp2 = inf -> NaN
+            // rows whose k / v then poison every later query of the sequence through 0 x NaN
+            const float m_ref = m_new <= -1e29f ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_run[w] <= -1e29f ? -1e30f : m_run[w] - m_ref) * scale_log2e);
             m_run[w] = m_new;
-            const float mb = m_new * scale_log2e;
+            const float mb = m_ref * scale_log2e;
             float psum = 0.f;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -275,8 +280,8 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
 #pragma unroll
     for (int w = 0; w < K::QW; ++w)
         if (q_idx[w] < T) {
-            // a query row whose keys are ALL masked (a padding position in front of a left-padded sequence) averaged the masked values
-            // with weight 1 each (exp2(0)): finite, and never read - the reference produces equally meaningless rows there
+            // a query row whose keys are ALL masked (a padding position in front of a left-padded sequence) has l = 0: it is written
+            // as zeros - finite, and never read (the reference produces equally meaningless rows there)
             const float inv = l_run[w] > 0.f ? 1.0f / l_run[w] : 0.f;
             bf16* orow = out + ((size_t)b * T + q_idx[w]) * ((size_t)nh * HD) + h * HD;
 #pragma unroll

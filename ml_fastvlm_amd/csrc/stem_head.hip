@@ -148,8 +148,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ img, bf16* __restrict__ out,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         int B, int R)
+                                                         int B, int R, int ntiles)
 {
+    // Round 3: a workgroup walks STEMF_TPW consecutive tiles (one every gridDim.x) instead of one: the weight fragment image and the
+    // stem[1] taps are built once, and the NEXT tile's 3 x 35 x 35 image pixels are loaded into registers while the current tile
+    // runs its two phases (one tile per workgroup spent most of its ~15 us waiting for that gather: 32768 workgroups x 3 barriers).
     constexpr int CO = 96;
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     bf16x8* wimg = (bf16x8*)smem_f;                              // [cb][s][lane]: 6 KiB
@@ -173,36 +176,36 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
     for (int i = tid; i < 9 * CO / 4; i += 256) *(f32x4*)&lw1[i * 4] = *(const f32x4*)&w1[i * 4];
 
     const int H1 = R / 2, H2 = R / 4, TXY = H2 / STEMF_T;        // stem[0] map side, stem[1] map side, tiles per side
-    const int tile = blockIdx.x;
-    const int tx = tile % TXY, ty = (tile / TXY) % TXY, b = tile / (TXY * TXY);
-    const int cy0 = 2 * ty * STEMF_T - 1, cx0 = 2 * tx * STEMF_T - 1;          // stem[0] coordinates of region position (0, 0)
-
-    // ---- phase 0: the 3 x 35 x 35 image pixels under the region, rounded to bf16 (the tower's compute dtype), zero outside
-    //      the image, into LDS: the im2col gather below is then two aligned ds_read_b32 per (channel, tap row) instead of
-    //      three bounds-checked 2-byte global loads with 64-bit addressing
-    {
-        const int iy0 = 2 * cy0 - 1, ix0 = 2 * cx0 - 1;
-        const T* ib = img + (size_t)b * 3 * R * R;
-        constexpr int NE = 3 * STEMF_IR * STEMF_IR, NIT = (NE + 255) / 256;     // 3675 elements, 15 per thread
-        float v[NIT];
+    constexpr int NE = 3 * STEMF_IR * STEMF_IR, NIT = (NE + 255) / 256;         // 3675 image elements under a region, 15 per thread
+    // ---- phase 0 (per tile, one tile ahead): the 3 x 35 x 35 image pixels under the region, rounded to bf16 (the tower's compute
+    //      dtype), zero outside the image; they go into LDS so that the im2col gather below is two aligned ds_read_b32 per (channel,
+    //      tap row) instead of three bounds-checked 2-byte global loads with 64-bit addressing
+    // raw element values + a validity bit mask: NO dependent operation until the values are written to LDS one tile later, so the
+    // loads really stay in flight across the two phases of the current tile (a select right behind the load would wait for it)
+    auto load_image = [&](int tile, T (&v)[NIT], unsigned& okmask) {
+        int ln = tid;
+        asm volatile("" : "+v"(ln));                              // opaque: keeps the 15 per-thread address chains out of the tile loop's live set
+        const int tx_ = tile % TXY, ty_ = (tile / TXY) % TXY, b_ = tile / (TXY * TXY);
+        const int iy0 = 2 * (2 * ty_ * STEMF_T - 1) - 1, ix0 = 2 * (2 * tx_ * STEMF_T - 1) - 1;
+        const T* ib = img + (size_t)b_ * 3 * R * R;
+        unsigned m = 0;
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {                           // all loads in flight before the first LDS write
-            const int e = i * 256 + tid;
+        for (int i = 0; i < NIT; ++i) {
+            const int e = i * 256 + ln;
             const int row = e / STEMF_IR, col = e - row * STEMF_IR;
             const int ci = row / STEMF_IR, r = row - ci * STEMF_IR;
             const int iy = iy0 + r, ix = ix0 + col;
             const bool ok = e < NE && iy >= 0 && iy < R && ix >= 0 && ix < R;
-            const float ld = ld_as_f32<T>(ib, ok ? (unsigned)((ci * R + iy) * R + ix) : 0u);
-            v[i] = ok ? ld : 0.0f;
+            v[i] = ib[ok ? (unsigned)((ci * R + iy) * R + ix) : 0u];
+            m |= ok ? (1u << i) : 0u;
         }
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int e = i * 256 + tid;
-            const int row = e / STEMF_IR, col = e - row * STEMF_IR;
-            if (e < NE) itile[row * STEMF_IS + col] = (bf16)v[i];
-        }
-    }
-    __syncthreads();
+        okmask = m;
+    };
+    T vimg[NIT];
+    unsigned okmask = 0;
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_image(tile, vimg, okmask);
+    __syncthreads();                                              // weight image + taps visible
     bf16x8 wa[3][2];
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb)
@@ -214,7 +217,25 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[cb][q] = *(const f32x4*)(b0 + cb * 32 + q * 8 + half * 4);
 
+#pragma unroll 1
+    for (; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % TXY, ty = (tile / TXY) % TXY, b = tile / (TXY * TXY);
+    const int cy0 = 2 * ty * STEMF_T - 1, cx0 = 2 * tx * STEMF_T - 1;          // stem[0] coordinates of region position (0, 0)
+    {
+        int ln = tid;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = i * 256 + ln;
+            const int row = e / STEMF_IR, col = e - row * STEMF_IR;
+            const float fv = ((okmask >> i) & 1u) ? ld_as_f32<T>(&vimg[i], 0) : 0.0f;
+            if (e < NE) itile[row * STEMF_IS + col] = (bf16)fv;
+        }
+    }
+    __syncthreads();                  // image tile complete; every thread is past phase 2 of the previous tile (`reg` may be rewritten)
+    if (tile + (int)gridDim.x < ntiles) load_image(tile + gridDim.x, vimg, okmask);    // in flight during both phases
     // ---- phase 1: the stem[0] region, 32 positions per MFMA tile
+#pragma unroll 1
     for (int t = wave; t * 32 < STEMF_NP; t += 4) {
         const int p = t * 32 + px;
         const int ry = p / STEMF_R, rx = p - ry * STEMF_R;
@@ -294,6 +315,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
         for (int c = 0; c < 8; ++c) r[c] = gelu_erf(acc[c]);
         *(bf16x8*)(out + (((size_t)b * H2 + ty * STEMF_T + oy) * H2 + tx * STEMF_T + ox) * CO + cg * 8) = f32_to_bf8(r);
     }
+    }   // tiles of this workgroup
 }
 
 // img [B,3,R,R] (dtype) -> out [B,R/4,R/4,96] bf16 = gelu(dw3x3s2(gelu(conv3x3s2(img) + b0)) + b1);  R % 64 == 0
@@ -303,7 +325,13 @@ extern "C" int fvhd_launch_stem_fused(hipStream_t st, const void* img, int dtype
     if (R % 64) return (int)hipErrorInvalidValue;
     const int txy = R / 4 / STEMF_T;
     const size_t shmem = 6 * 64 * 16 + 9 * 96 * 4 + STEMF_IB + (size_t)STEMF_NP * STEMF_PS;
-    dim3 grid((unsigned)((size_t)B * txy * txy)), block(256);
+    const long ntiles = (long)B * txy * txy;
+    if (ntiles > 0x7fffffffl) return (int)hipErrorInvalidValue;
+    // STEMF_TPW tiles per workgroup, strided by the grid (tile, tile + G, ...): neighbouring workgroups work on neighbouring tiles at
+    // the same time (halo pixels hit L2), the tail is at most one tile per workgroup
+    constexpr int STEMF_TPW = 4;
+    const long G = ntiles >= 4 * 512 * STEMF_TPW ? (ntiles + STEMF_TPW - 1) / STEMF_TPW : ntiles;
+    dim3 grid((unsigned)G), block(256);
     static bool attr_set[64][3];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -315,7 +343,7 @@ extern "C" int fvhd_launch_stem_fused(hipStream_t st, const void* img, int dtype
             if (e != hipSuccess) return (int)e;                                                                                \
             attr_set[dev & 63][IDX] = true;                                                                                    \
         }                                                                                                                      \
-        hipLaunchKernelGGL(stem_fused_kernel<TT>, grid, block, shmem, st, (const TT*)img, (bf16*)out, w0, b0, w1, b1, B, R);    \
+        hipLaunchKernelGGL(stem_fused_kernel<TT>, grid, block, shmem, st, (const TT*)img, (bf16*)out, w0, b0, w1, b1, B, R, (int)ntiles); \
     } while (0)
     if (dtype == FVHD_F32) STEMF_LAUNCH(float, 0);
     else if (dtype == FVHD_F16) STEMF_LAUNCH(_Float16, 1);

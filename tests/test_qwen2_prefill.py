@@ -185,7 +185,8 @@ def test_rope_in_place_and_kv_cache(hd, nh, nkv):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("hd,nh,nkv,B,T,pad", [(64, 14, 2, 3, 285, "none"), (64, 4, 2, 4, 130, "left"), (64, 2, 1, 2, 64, "right"),
-                                              (128, 4, 2, 2, 200, "left"), (128, 2, 2, 3, 17, "none"), (64, 2, 2, 1, 1, "none")])
+                                              (128, 4, 2, 2, 200, "left"), (128, 2, 2, 3, 17, "none"), (64, 2, 2, 1, 1, "none"),
+                                              (64, 2, 1, 5, 300, "left")])        # left padding of up to 97 positions: whole key tiles masked
 def test_causal_gqa_attention(hd, nh, nkv, B, T, pad):
     lib = _lib.load()
     g = torch.Generator().manual_seed(T + hd)
@@ -222,26 +223,24 @@ def test_gemm_swiglu_and_residual_epilogues():
         Wd = _bf(torch.randn(K, I, generator=g) * I ** -0.5)
         act = _bf(torch.randn(M, I, generator=g))
         res = _bf(torch.randn(M, K, generator=g))
-        rd = res.to(DEV, torch.bfloat16)
-        _lib.check(lib.fvhd_op_gemm(_stream(), _p(act.to(DEV, torch.bfloat16)), _p(Wd.to(DEV, torch.bfloat16)), _p(None), _p(None), _p(rd), _p(rd),
-                                    M, K, I, _lib.EPI_RESID, _lib.BF16), "resid")
+        rd, actd, wdd = res.to(DEV, torch.bfloat16), act.to(DEV, torch.bfloat16), Wd.to(DEV, torch.bfloat16)     # (named: alive until the sync)
+        _lib.check(lib.fvhd_op_gemm(_stream(), _p(actd), _p(wdd), _p(None), _p(None), _p(rd), _p(rd), M, K, I, _lib.EPI_RESID, _lib.BF16), "resid")
         torch.cuda.synchronize()
         _close(rd, res + act @ Wd.t(), f"resid {M}x{I}x{K}")
     # split-K (down_proj at the prefill shape): partial sums in slice order + residual, one rounding
     for M, N, K, splits in ((2304, 896, 4864, 4), (300, 128, 512, 2), (256, 256, 256, 1)):
         A, W, res = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5), _bf(torch.randn(M, N, generator=g))
-        rd = res.to(DEV, torch.bfloat16)
+        rd, ad, wd = res.to(DEV, torch.bfloat16), A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16)
         part = torch.empty(splits * M * N, device=DEV, dtype=torch.float32)
-        _lib.check(lib.fvhd_op_gemm_splitk(_stream(), _p(A.to(DEV, torch.bfloat16)), _p(W.to(DEV, torch.bfloat16)), _p(rd), _p(rd), _p(part), M, N, K, splits),
-                   "splitk")
+        _lib.check(lib.fvhd_op_gemm_splitk(_stream(), _p(ad), _p(wd), _p(rd), _p(rd), _p(part), M, N, K, splits), "splitk")
         torch.cuda.synchronize()
         _close(rd, res + A @ W.t(), f"split-K {M}x{N}x{K}/{splits}")
     # fp32 logits without bias (lm_head), few rows
     A = _bf(torch.randn(8, 896, generator=g))
     W = _bf(torch.randn(1024, 896, generator=g) * 896 ** -0.5)
     out = torch.empty(8, 1024, device=DEV, dtype=torch.float32)
-    _lib.check(lib.fvhd_op_gemm(_stream(), _p(A.to(DEV, torch.bfloat16)), _p(W.to(DEV, torch.bfloat16)), _p(None), _p(None), _p(None), _p(out),
-                                8, 1024, 896, _lib.EPI_NONE, _lib.F32), "lm_head gemm")
+    ad, wd = A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16)
+    _lib.check(lib.fvhd_op_gemm(_stream(), _p(ad), _p(wd), _p(None), _p(None), _p(None), _p(out), 8, 1024, 896, _lib.EPI_NONE, _lib.F32), "lm_head gemm")
     torch.cuda.synchronize()
     _close(out, A @ W.t(), "fp32 logits", rtol=2e-3, atol_rms=2e-3)
 
