@@ -101,13 +101,10 @@ class MobileCLIPVisionTower(nn.Module):
         self.vision_tower_name = vision_tower
         self.tune_vision_tower = getattr(args, "unfreeze_mm_vision_tower", False)
         self.input_image_size = int(vision_tower.split("_")[-1])
-        # MI355X-only option (no counterpart in the reference): e4m3 MFMA operands in the MHSA core, the "fp8 MFMA attention
-        # path" of BASELINE.json configs[4]; read from the config object like the reference reads its own switches
-        # Tri-state: None = leave the library's setting alone (fvhd_create reads FVHD_ATTN_FP8 / FVHD_GRAPH from the environment,
+        # MI355X-only options (no counterpart in the reference), read from the config object like the reference reads its own
+        # switches.  Tri-state: None = leave the library's setting alone (fvhd_create reads FVHD_GRAPH from the environment,
         # INTEGRATION.md); True / False = explicit, pushed to the context before every call.
-        fp8 = getattr(args, "mm_vision_attention_fp8", None)
-        self.attention_fp8 = None if fp8 is None else bool(fp8)
-        # ... and hipGraph replay of the tower's interior launches (include/fvhd.h: fvhd_set_graph), for launch-bound batches
+        # hipGraph replay of the tower's interior launches (include/fvhd.h: fvhd_set_graph), for launch-bound batches
         graph = getattr(args, "mm_vision_hip_graph", None)
         self.hip_graph = None if graph is None else bool(graph)
         inv = getattr(args, "mm_vision_batch_invariant", None)
@@ -181,8 +178,6 @@ class MobileCLIPVisionTower(nn.Module):
                     self._ctx.set_tensor(k, v)
             self._ctx.finalize()
             self._dirty = False
-        if self.attention_fp8 is not None:
-            self._ctx.set_attention_fp8(self.attention_fp8)
         if self.hip_graph is not None:
             self._ctx.set_graph(self.hip_graph)
         if self.batch_invariant is not None:

@@ -45,14 +45,15 @@ def test_delay_load_with_unfreeze_loads_eagerly():
 
 
 def test_mi355x_options_default_off_and_read_from_args():
-    """The two options that have no counterpart in the reference are opt-in, so a reference config object
+    """The options that have no counterpart in the reference are opt-in, so a reference config object
     that knows nothing about them builds the parity path."""
     t = fv.MobileCLIPVisionTower("mobileclip_l_256", ARGS, delay_load=True)
-    assert t.attention_fp8 is None and t.hip_graph is None      # tri-state: None = "not set here" (the library default is off and its
-    #                                                             environment switches FVHD_ATTN_FP8 / FVHD_GRAPH stay in force)
-    t = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_attention_fp8=True,
+    assert t.hip_graph is None and t.batch_invariant is None    # tri-state: None = "not set here" (the library default is off and its
+    #                                                             environment switch FVHD_GRAPH stays in force)
+    t = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_batch_invariant=True,
                                                                     mm_vision_hip_graph=1), delay_load=True)
-    assert t.attention_fp8 is True and t.hip_graph is True
+    assert t.batch_invariant is True and t.hip_graph is True
+    assert not hasattr(t, "attention_fp8")                      # the e4m3 attention option of rounds 1-2 is gone (DESIGN.md "fp8")
 
 
 def test_unknown_names_raise_value_error():
