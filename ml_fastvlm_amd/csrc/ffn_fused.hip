@@ -339,15 +339,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 #define FFN_SYNC() ffn_wait_dma(); __syncthreads()
 #define FFN_B1PREV(cur) ((cur) == lb1 ? lb1 + (NCH - 1) * 32 : (cur) - 32)     // b1 of the chunk before `cur` (cyclic)
     FFN_SYNC();
-    ffn_iter<C, NB, WAVES, true, false, false, true, VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(0));
+    ffn_iter<C, NB, WAVES, true, false, false, !(VAR & 1), VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(0));
     FFN_SYNC();
-    ffn_iter<C, NB, WAVES, true, true, false, true, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + 32, FFN_B1PREV(lb1 + 32), half, FFN_DMA_ARGS(1));
+    ffn_iter<C, NB, WAVES, true, true, false, !(VAR & 1), VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + 32, FFN_B1PREV(lb1 + 32), half, FFN_DMA_ARGS(1));
 #pragma unroll 1
     for (int t = 2; t < NCH; t += 2) {
         FFN_SYNC();                  // even t: S(t) -> s0, GELU(s1) -> p1, GEMM2 reads p0
-        ffn_iter<C, NB, WAVES, true, true, true, true, VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1 + t * 32, FFN_B1PREV(lb1 + t * 32), half, FFN_DMA_ARGS(t));
+        ffn_iter<C, NB, WAVES, true, true, true, !(VAR & 1), VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1 + t * 32, FFN_B1PREV(lb1 + t * 32), half, FFN_DMA_ARGS(t));
         FFN_SYNC();                  // odd t:  S(t) -> s1, GELU(s0) -> p0, GEMM2 reads p1
-        ffn_iter<C, NB, WAVES, true, true, true, true, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + (t + 1) * 32, FFN_B1PREV(lb1 + (t + 1) * 32), half, FFN_DMA_ARGS(t + 1));
+        ffn_iter<C, NB, WAVES, true, true, true, !(VAR & 1), VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + (t + 1) * 32, FFN_B1PREV(lb1 + (t + 1) * 32), half, FFN_DMA_ARGS(t + 1));
     }
     // the residual tile of X is fetched now, coalesced like A^T above (the A^T registers are dead from here on), so that
     // its HBM latency hides behind the last two pipeline iterations instead of stalling the epilogue
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     }
     }
     FFN_SYNC();                      // t = NCH (even): GELU(S(NCH-1) in s1) -> p1, GEMM2(chunk NCH-2) reads p0; DMA W2[NCH-1]
-    ffn_iter<C, NB, WAVES, false, true, true, true, VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
+    ffn_iter<C, NB, WAVES, false, true, true, !(VAR & 1), VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
     FFN_SYNC();                      // t = NCH + 1: GEMM2(chunk NCH-1) reads p1
     ffn_iter<C, NB, WAVES, false, false, true, false, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
 #undef FFN_DMA_ARGS
@@ -510,6 +510,24 @@ extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* 
     bf16* x = (bf16*)X;
     hipError_t e = hipErrorInvalidValue;
     if (M <= 0) return (int)e;
+#ifdef FVHD_FFN_ABLATE
+    // ablation build only (libfvhd_ablate.so): FVHD_FFN_VARIANT = 1 PF 4, 2 no GELU math (wrong results), 3 compiler-scheduled iteration,
+    // 4 scalar GELU, 5 PF 2, 6 no weight DMA (wrong results), 7 no GELU + no DMA
+    static const int variant = [] { const char* ev = getenv("FVHD_FFN_VARIANT"); return ev ? atoi(ev) : 0; }();
+#define FFN_V(CC, OCC)                                                                                                  \
+    switch (variant) {                                                                                                 \
+    case 1: return (int)launch_ffn<CC, 1, 4, 0, 4, OCC>(st, a, w1, w2, b1, b2, ls, x, M);                              \
+    case 2: return (int)launch_ffn<CC, 1, 4, 2, 3, OCC>(st, a, w1, w2, b1, b2, ls, x, M);                              \
+    case 3: return (int)launch_ffn<CC, 1, 4, 16, 3, OCC>(st, a, w1, w2, b1, b2, ls, x, M);                             \
+    case 4: return (int)launch_ffn<CC, 1, 4, 64, 3, OCC>(st, a, w1, w2, b1, b2, ls, x, M);                             \
+    case 5: return (int)launch_ffn<CC, 1, 4, 0, 2, OCC>(st, a, w1, w2, b1, b2, ls, x, M);                              \
+    case 6: return (int)launch_ffn<CC, 1, 4, 1, 3, OCC>(st, a, w1, w2, b1, b2, ls, x, M);                              \
+    case 7: return (int)launch_ffn<CC, 1, 4, 3, 3, OCC>(st, a, w1, w2, b1, b2, ls, x, M);                              \
+    default: break;                                                                                                    \
+    }
+    if (C == 384) { FFN_V(384, 1) } else if (C == 192) { FFN_V(192, 2) } else if (C == 96) { FFN_V(96, 3) }
+#undef FFN_V
+#endif
     if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
     else if (C == 192) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
     // C = 96: 152 registers since the epilogue offsets stopped being hoisted -> three workgroups (waves) per SIMD: the kernel is

@@ -283,6 +283,118 @@ __global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
     gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 16 * MF, n0 + wn * 64, lr, g);
 }
 
+// v4 (round 3, experiment): "ping-pong" 256 x 256 tile.  The 8 waves form two groups (rows 0-127 / 128-255 of the tile; one wave of each
+// group per SIMD) that run ONE PHASE APART: while a group issues the fragment reads of a half K-tile (12 ds_read_b128 per wave) and its
+// LDS-DMA pieces, the other group runs the 32 MFMAs of its own half K-tile out of registers, and a barrier ends every phase - each
+// SIMD's matrix pipe always has a wave in its MFMA phase, the LDS / DMA work hides behind the partner's MFMAs (the schedule of
+// cdna_hip_programming.md's 8-phase template, with half-K-tile phases).  Phases of group 0: L(t,0) M(t,0) L(t,1) M(t,1) = 4t .. 4t+3;
+// group 1 is shifted by one.  K-tile t lives in stage t % 2 (64 KB: A 256 x 64, W 256 x 64, same XOR-swizzled image as v2 / v3);
+// its last reader is group 1's L(t,1) in phase 4t+3, so the DMA of tile t+2 into the same stage is issued in phases 4t+4 / 4t+5 (4 + 4
+// pieces per wave) and waited for (vmcnt(0)) before the barrier that ends phase 4t+7 - at least two phases of flight.
+template <int EPI, int ODT>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ ls, const bf16* resid, void* out, int M, int N, int K, int tiles_n, int nwg)
+{
+    constexpr int BM = 256, BN = 256, BK = 64, MF = 8, NF = 4, STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;               // group = M half; four waves side by side in N
+    const int lr = lane & 15, g = lane >> 4;
+    const int L = xcd_remap(blockIdx.x, nwg);
+    constexpr int GN = 4;
+    const int tiles_m = nwg / tiles_n;
+    const int sg = L / (tiles_m * GN), rem = L - sg * tiles_m * GN;
+    const int wgw = min(GN, tiles_n - sg * GN);
+    const int tm = rem / wgw, tn = sg * GN + (rem - tm * wgw);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // DMA: K-tile = 32 A pieces + 32 W pieces of 1 KiB (8 rows x 128 B); wave w owns A pieces 4w .. 4w+3 and W pieces 4w .. 4w+3
+    const int rip = lane >> 3;
+    unsigned vo[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int sw = ((par * 8 + rip) >> 1) & 7;
+        vo[par] = (unsigned)((rip * K + (((lane & 7) ^ sw) * 8)) * 2);
+    }
+    const char* abase = (const char*)(A + (size_t)(m0 + wave * 32) * K);
+    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * 32) * K);
+    const unsigned lds0 = lds_addr(lds2);
+    auto issue4 = [&](int kt, int which) {                  // which = 0: this wave's 4 A pieces, 1: its 4 W pieces
+        const unsigned st = lds0 + (kt & 1) * STAGE + (which ? 256 * 128 : 0) + wave * 4096;
+        const char* base = (which ? wbase : abase) + (size_t)kt * BK * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds_piece(vo[j & 1], base + (size_t)j * 8 * K * 2, st + j * 1024);
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[MF], wf[NF];
+
+    const int nk = K / BK;
+    issue4(0, 0); issue4(0, 1);
+    if (nk > 1) { issue4(1, 0); issue4(1, 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one phase behind: this is its phase 0 (idle)
+
+    auto load_phase = [&](int kt, int h) {                  // fragment reads of half K-tile (kt, h): k-slots 4h .. 4h+3
+        const char* ldsA = lds2 + (kt & 1) * STAGE;
+        const char* ldsW = ldsA + 256 * 128;
+        const int ks = h * 4 + g;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) wf[j] = *(const bf16x8*)(ldsW + lds_off<BK>(wn * 64 + j * 16 + lr, ks));
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(ldsA + lds_off<BK>(grp * 128 + i * 16 + lr, ks));
+    };
+    auto mfma_phase = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // End of a phase: own LDS reads complete (the stage may be overwritten two barriers from now), optionally own DMA complete.
+#define PP_END(WAIT_VM)                                                                           \
+    do {                                                                                          \
+        if (WAIT_VM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_s_barrier();                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // DMA schedule (tiles 0 and 1 came with the prologue).  Tile kt + 1 goes into the stage of tile kt - 1, free from global phase
+        // 4kt on; it must have landed by the barrier that ends phase 4kt + 3.  Group 0 (phases 4kt, 4kt+1 = its L / M(kt, 0)) issues its A
+        // pieces in L(kt, 0) and its W pieces in M(kt, 0); group 1 (phases 4kt, 4kt+1 = its M(kt-1, 1) / L(kt, 0)) issues the A pieces of
+        // tile kt + 2 in M(kt, 1) and the W pieces of tile kt + 1 in L(kt, 0): every piece has two phases of flight before its wait.
+        const bool d1 = kt >= 1 && kt + 1 < nk, d2 = kt + 2 < nk;
+        // ---- L(kt, 0)
+        load_phase(kt, 0);
+        if (d1) issue4(kt + 1, grp == 0 ? 0 : 1);
+        PP_END(false);
+        // ---- M(kt, 0)
+        mfma_phase();
+        if (d1 && grp == 0) issue4(kt + 1, 1);
+        PP_END(false);
+        // ---- L(kt, 1)
+        load_phase(kt, 1);
+        PP_END(grp == 1);                                   // group 1: A(kt+1) (issued in M(kt-1, 1)) and W(kt+1) have landed
+        // ---- M(kt, 1)
+        mfma_phase();
+        if (d2 && grp == 1) issue4(kt + 2, 0);
+        PP_END(grp == 0);                                   // group 0: A(kt+1), W(kt+1) have landed
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();             // group 0 matches group 1's extra phase
+#undef PP_END
+    gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + grp * 128, n0 + wn * 64, lr, g);
+}
+
 #ifdef FVHD_DEBUG_KNOBS                 // A/B runs (tools/bench_ops.py gemm on libfvhd_ablate.so): 0 = always the v1 kernel
 static int g_gemm_v2 = 1;
 extern "C" void fvhd_debug_set_gemm_v2(int on) { g_gemm_v2 = on; }
@@ -305,6 +417,38 @@ static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, 
     const int tiles_m = M / 256, tiles_n = N / BN, nwg = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN>), dim3(nwg), dim3(64 * NWV), G2Cfg<BN>::LDS, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
     return hipGetLastError();
+}
+
+template <int EPI, int ODT>
+static hipError_t launch_gemm_pp(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
+                                 const bf16* resid, void* out, int M, int N, int K)
+{
+    constexpr int LDS = 2 * 512 * 128;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, ODT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    const int tiles_m = M / 256, tiles_n = N / 256, nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, ODT>), dim3(nwg), dim3(512), LDS, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+    return hipGetLastError();
+}
+
+static hipError_t dispatch_gemm_pp(hipStream_t st, const bf16* a, const bf16* w, const float* bias, const float* ls, const bf16* r, void* out,
+                                   int M, int N, int K, int epi)
+{
+    switch (epi) {
+    case EPI_NONE: return launch_gemm_pp<EPI_NONE, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS: return launch_gemm_pp<EPI_BIAS, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_GELU: return launch_gemm_pp<EPI_BIAS_GELU, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_LS_RESID: return launch_gemm_pp<EPI_BIAS_LS_RESID, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_RESID: return launch_gemm_pp<EPI_RESID, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_SWIGLU: return launch_gemm_pp<EPI_SWIGLU, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int BN>
@@ -399,7 +543,8 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     // (tools/bench_ops.py gemm, profiles/r02_gemm_v1_v2.log) fc1 272 -> 264 us, fc2 (K = 3072) 215 -> 196, stage-5 qkv 177 -> 155,
     // projector fc 68 -> 56; with 384 tiles (stage-5 proj / fc2, 1.5 rounds) v1 stays ahead.  A 4-wave variant with 128 x 64 per
     // wave (fewer fragment reads, one wave per SIMD) was 10-25 % slower: nothing covers the LDS read latency.
-    // g_gemm_v2 (debug build): 0 = v1 only, 1 = the rule below, 2 = the 256 x 128 tile wherever it is legal, 3 = the 256 x 256 tile wherever legal
+    // g_gemm_v2 (debug build): 0 = v1 only, 1 = the rule below, 2 = the 256 x 128 tile wherever it is legal, 3 = the 256 x 256 tile wherever legal,
+    // 4 = the ping-pong 256 x 256 kernel wherever legal
     if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128) {
         const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
         // measured (tools/bench_ops.py gemm, profiles/r03_gemm_tiles.log, B = 32): the 256 x 256 tile wins from N = 2304 on when it has
@@ -408,6 +553,7 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
         // produce identical bits (same K order per output element).
         const bool use256 = g_gemm_v2 == 3 ? t256 > 0 : (g_gemm_v2 == 1 && N >= 2304 && t256 >= 448);
         const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && t128 >= 512);
+        if (g_gemm_v2 == 4 && t256 > 0) return (int)dispatch_gemm_pp(st, a, w, bias, ls, r, out, M, N, K, epi);     // ping-pong experiment
         if (use256) return (int)dispatch_gemm256<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
         if (use128) return (int)dispatch_gemm256<128>(st, a, w, bias, ls, r, out, M, N, K, epi);
     }
