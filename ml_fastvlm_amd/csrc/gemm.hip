@@ -553,7 +553,10 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
         // produce identical bits (same K order per output element).
         const bool use256 = g_gemm_v2 == 3 ? t256 > 0 : (g_gemm_v2 == 1 && N >= 2304 && t256 >= 448);
         const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && t128 >= 512);
-        if (g_gemm_v2 == 4 && t256 > 0) return (int)dispatch_gemm_pp(st, a, w, bias, ls, r, out, M, N, K, epi);     // ping-pong experiment
+        // ping-pong kernel: same tile, +0-6 % over the plain 256 x 256 kernel, the more the longer K (profiles/r03_gemm_tiles.log: stage-4 fc2
+        // K = 6144 185 -> 177 us, 7B projector K = 3584 243 -> 228 us = 0.92 PF/s; K = 768 shapes tie) - taken for K >= 3072
+        if ((g_gemm_v2 == 4 && t256 > 0) || (g_gemm_v2 == 1 && K >= 3072 && t256 >= 128))
+            return (int)dispatch_gemm_pp(st, a, w, bias, ls, r, out, M, N, K, epi);
         if (use256) return (int)dispatch_gemm256<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
         if (use128) return (int)dispatch_gemm256<128>(st, a, w, bias, ls, r, out, M, N, K, epi);
     }
