@@ -245,7 +245,7 @@ template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void ffn_fused_kernel(
     const bf16* __restrict__ A, const char* __restrict__ w1img, const char* __restrict__ w2img,
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ ls,
-    bf16* X, int M, int nwg, int first_gen, int stagger_cycles)
+    bf16* X, int M, int nwg)
 {
     constexpr int HID = 4 * C, KS = C / 16, NFR = C / 32, NCH = HID / 32;
     constexpr int CHB = 64 * C;             // bytes of one W1 (or W2) chunk image
@@ -260,15 +260,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
     const int blk = xcd_remap(blockIdx.x, nwg);
-    // Stagger.  Every workgroup takes the same time, so the whole chip marches in lockstep: all CUs stream their A / X tiles and store
-    // their outputs at the same moments (HBM saturated, matrix pipes idle) and all run their chunk loops together (HBM idle) - the
-    // 26-40 % "fixed cost" of this kernel.  Half of the FIRST generation of workgroups (alternate CUs of every XCD) starts
-    // `stagger_cycles` late; from then on a CU starts its next workgroup when its previous one ends, so the two halves stay out of
-    // phase for the whole launch and each half's memory phase falls into the other's chunk loop.
-    if (stagger_cycles > 0 && (int)blockIdx.x < first_gen && ((blockIdx.x >> 3) & 1)) {
-        const long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < stagger_cycles) __builtin_amdgcn_s_sleep(32);
-    }
     const int row0 = blk * (32 * NB * WAVES) + wave * (32 * NB);
     const int uwave = __builtin_amdgcn_readfirstlane(wave);          // provably uniform: DMA bases stay in SGPRs / M0
     const unsigned lds_w1 = __builtin_amdgcn_readfirstlane(lds_addr(w1ring)), lds_w2 = __builtin_amdgcn_readfirstlane(lds_addr(w2ring));
@@ -455,28 +446,6 @@ template <typename K> static hipError_t ffn_set_lds(K kernel, size_t shmem, bool
     return e;
 }
 
-static int ffn_cus()
-{
-    static int n[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!n[dev & 63]) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n[dev & 63] = v;
-    }
-    return n[dev & 63];
-}
-
-// start-up delay (shader cycles, ~2 GHz) of the odd half of the first generation; 0 = lockstep.  FVHD_FFN_STAGGER_US overrides (A/B runs).
-static int ffn_stagger_cycles(int C)
-{
-    static const int env_us = [] { const char* e = getenv("FVHD_FFN_STAGGER_US"); return e ? atoi(e) : -1; }();
-    if (env_us >= 0) return env_us * 2000;
-    (void)C;
-    return 0;          // (default set after the measurement of round 3, see profiles/)
-}
-
 template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
 static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, const char* w2img, const float* b1,
                              const float* b2, const float* ls, bf16* X, int M)
@@ -487,11 +456,10 @@ static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, c
     static bool attr_set[64];                // the attribute is per device
     hipError_t e = ffn_set_lds(ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>, shmem, attr_set);
     if (e != hipSuccess) return e;
-    // first generation = the workgroups resident at launch (OCC workgroups of 4 waves per CU); stagger only when there are >= 2 generations
-    const int first_gen = ffn_cus() * OCC;
-    const int stagger = nwg >= 2 * first_gen ? ffn_stagger_cycles(C) : 0;
-    hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg,
-                       first_gen, stagger);
+    // (Round 3 tried starting half of the first generation of workgroups 6-45 us late so that the memory phases of one half of the chip fall
+    // into the chunk loops of the other: no gain in sustained operation - 354 / 369 / 493 us per launch at C = 384 / 192 / 96 with or
+    // without, the whole step 26.83 -> 26.84 .. 27.4 ms - back-to-back launches already overlap at their tails; profiles/r03_ffn_stagger.log.)
+    hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
     return hipGetLastError();
 }
 

@@ -31,10 +31,10 @@ CLASSES = [  # (class, regex on kernel name); first match wins
     ("stem", r"stem_(fused|conv)_kernel|dwconv_tiled_kernelILi3ELi2ELi1E"),
     ("attention", r"attention_kernel"),
     ("layernorm", r"layernorm_kernel"),
-    ("gemm_gelu (fc1 / 1x1 / proj0)", r"gemm256_kernel<2,|gemm256_kernelILi2E"),          # streaming kernel: template <EPI, ODT, NWV>
-    ("gemm_resid (fc2 / proj)", r"gemm256_kernel<3,|gemm256_kernelILi3E"),
-    ("gemm_plain (qkv)", r"gemm256_kernel<0,|gemm256_kernelILi0E"),
-    ("gemm_bias (proj2)", r"gemm256_kernel<1,|gemm256_kernelILi1E"),
+    ("gemm_gelu (fc1 / 1x1 / proj0)", r"gemm(256|_pp)_kernel<2,|gemm(256|_pp)_kernelILi2E"),          # streaming / ping-pong kernels: template <EPI, ODT, ...>
+    ("gemm_resid (fc2 / proj)", r"gemm(256|_pp)_kernel<3,|gemm(256|_pp)_kernelILi3E"),
+    ("gemm_plain (qkv)", r"gemm(256|_pp)_kernel<0,|gemm(256|_pp)_kernelILi0E"),
+    ("gemm_bias (proj2)", r"gemm(256|_pp)_kernel<1,|gemm(256|_pp)_kernelILi1E"),
     ("gemm_gelu (fc1 / 1x1 / proj0)", r"gemm\w*_kernel<\d+, \d+, 2,|gemm\w*_kernelILi\d+ELi\d+ELi2E"),
     ("gemm_resid (fc2 / proj)", r"gemm\w*_kernel<\d+, \d+, 3,|gemm\w*_kernelILi\d+ELi\d+ELi3E"),
     ("gemm_plain (qkv)", r"gemm\w*_kernel<\d+, \d+, 0,|gemm\w*_kernelILi\d+ELi\d+ELi0E"),
