@@ -68,7 +68,7 @@ def library_projector(vision_tower, mm_projector) -> bool:
     and no gradient wanted through it (the HIP path is inference-only; a trainable projector under grad mode keeps autograd's
     nn.Sequential, as the reference's training does)."""
     return (isinstance(vision_tower, MobileCLIPVisionTower) and _is_mlp2x_gelu(mm_projector)
-            and mm_projector[0].weight.device == vision_tower.device and vision_tower.device.type == "cuda"
+            and mm_projector[0].weight.device == vision_tower.device
             and not (torch.is_grad_enabled() and any(p.requires_grad for p in mm_projector.parameters())))
 
 
