@@ -32,6 +32,11 @@ EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll
                "dwconv_mfma.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
+# experiment (FVHD_VARIANT_TAG=nopk): no packed fp32 VALU at all in the kernels that run VALU work beside MFMAs
+NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+NOPK_FILES = ("ffn_fused.hip", "attention.hip", "llm.hip", "gemm.hip", "stem_head.hip")
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -67,7 +72,7 @@ def build_library(force: bool = False, verbose: bool = False, ablate: bool = Fal
         o = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            extra = EXTRA_FLAGS.get(src, []) + list(defs) + (["-DFVHD_DEBUG_KNOBS"] if ablate else []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
+            extra = EXTRA_FLAGS.get(src, []) + (NOPK if tag == "nopk" and src in NOPK_FILES else []) + list(defs) + (["-DFVHD_DEBUG_KNOBS"] if ablate else []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
             jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -137,13 +137,16 @@ int upload_vector_f32(const void* host, int dtype, size_t n, char* dst)
 int ensure_ws(fvhd_llm* c, int B, int T, hipStream_t st, bool check_capture)
 {
     const int rows = (int)(((size_t)B * T + 255) / 256 * 256);
-    if (c->ws && rows <= c->ws_rows && B <= c->ws_batch && T <= c->ws_pos) return 0;
+    if (c->ws && rows <= c->ws_rows && B <= c->ws_batch && T <= c->ws_pos) return 0;      // (ws_pos >= 8192 once allocated)
     if (check_capture) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
             return lfail("fvhd_llm_prefill: the workspace must grow for this (batch, length) but the stream is being captured - call fvhd_llm_reserve first");
     }
-    const int nrows = rows > c->ws_rows ? rows : c->ws_rows, nb = B > c->ws_batch ? B : c->ws_batch, np = T > c->ws_pos ? T : c->ws_pos;
+    // the rotary table covers at least 8192 positions (2 MB at head_dim 64): position ids of a prefill are < seq_len, but a caller that
+    // continues a longer context may pass larger ones; the kernel clamps beyond the table
+    const int tpos = T > 8192 ? T : 8192;
+    const int nrows = rows > c->ws_rows ? rows : c->ws_rows, nb = B > c->ws_batch ? B : c->ws_batch, np = tpos > c->ws_pos ? tpos : c->ws_pos;
     const int lb = (nb + 15) / 16 * 16;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };

@@ -24,10 +24,26 @@ p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 stream = lambda: C.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
 
 
+def _pci_bus_id():
+    """PCI address of HIP device 0 (the box exposes several cards in sysfs; only one is ours)"""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+            return buf.value.decode().lower()
+    except OSError:
+        pass
+    return None
+
+
 def _sysfs():
-    for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+    bus = _pci_bus_id()
+    cands = glob.glob(f"/sys/bus/pci/devices/{bus}/hwmon/hwmon*") if bus else []
+    cands += glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
+    for hw in cands:
         pw = [f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))]
         if pw:
+            print(f"[power_probe] HIP device 0 = PCI {bus}; reading {hw}/{pw[0]}", file=sys.stderr)
             return os.path.join(hw, pw[0]), (os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None), \
                 (os.path.join(hw, "power1_cap") if os.path.exists(os.path.join(hw, "power1_cap")) else None)
     return None, None, None
