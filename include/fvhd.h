@@ -174,7 +174,10 @@ int fvhd_op_se_head(fvhd_stream_t stream, const void* y, float* pooled, float* s
  * w1img / w2img: DEVICE copies of the bf16 chunk images fvhd_ffn_pack writes on the host from fc1.weight [4C][C] and
  * fc2.weight [C][4C] (fp32, the reference's layouts): per chunk of 32 hidden units a 64*C-byte image in the kernel's
  * LDS byte order (XOR-swizzled 16-B slots; fc2's hidden axis permuted inside the chunk so that position 16kb+8half+j
- * holds hidden unit 16kb+8(j>>2)+4half+(j&3)).  Sizes: w1img (4C/32 + 1) * 64*C bytes (last chunk zero), w2img 4C/32 * 64*C. */
+ * holds hidden unit 16kb+8(j>>2)+4half+(j&3)).  Sizes: w1img (4C/32 + 1) * 64*C bytes (last chunk zero), w2img 4C/32 * 64*C.
+ * Element types of the images (half-precision GELU, csrc/ffn_fused.hip): bf16(fc1 / 4) and IEEE half f16(4 * fc2) - the kernel's
+ * hidden activation is gelu(x) / 4 in f16 (11 mantissa bits instead of bf16's 8; |Phi error| <= 1.4e-3; saturates at
+ * |x| = 262016).  The images are opaque to callers: pack with fvhd_ffn_pack of the same library build. */
 int fvhd_ffn_fused_supported(int C);
 int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img);
 int fvhd_op_ffn_fused(fvhd_stream_t stream, const void* A, const void* w1img, const float* b1, const void* w2img,

@@ -27,14 +27,15 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # -pragma-unroll-threshold: the 48-slot software pipeline of ffn_fused.hip must be FULLY unrolled (all register-array
 # indices compile-time); above the default 16 K-instruction threshold LLVM silently keeps a loop and the accumulators
 # land in scratch (2.7 KB/lane).
-EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"],
+# -packed-fp32-ops (round 3): no v_pk_*_f32 at all in the kernels whose VALU work runs beside MFMAs - the explicit f32x2 code of the
+# GELU / softmax still produced 50-90 of them per loop body, and two behind one MFMA turn a 33-cycle slot into 60 cycles
+# (tools/ubench/f16_rate.hip "shadow"); bit-identical results, -1 % on the fused FFN, -2 % on attention (profiles/r03_nopk_ab.log).
+# (the host pass prints "'-packed-fp32-ops' is not a recognized feature for this target": it is a device feature, harmless)
+NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"] + NOPK,
+               "attention.hip": NOPK, "llm.hip": NOPK,
                # dwconv_mfma.hip: 7 x 84 hand-placed MFMA slots, every register-array index compile-time (768 B/lane of scratch otherwise)
                "dwconv_mfma.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
-
-
-# experiment (FVHD_VARIANT_TAG=nopk): no packed fp32 VALU at all in the kernels that run VALU work beside MFMAs
-NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-NOPK_FILES = ("ffn_fused.hip", "attention.hip", "llm.hip", "gemm.hip", "stem_head.hip")
 
 
 def _hipcc() -> str:
@@ -72,7 +73,7 @@ def build_library(force: bool = False, verbose: bool = False, ablate: bool = Fal
         o = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            extra = EXTRA_FLAGS.get(src, []) + (NOPK if tag == "nopk" and src in NOPK_FILES else []) + list(defs) + (["-DFVHD_DEBUG_KNOBS"] if ablate else []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
+            extra = EXTRA_FLAGS.get(src, []) + list(defs) + (["-DFVHD_DEBUG_KNOBS"] if ablate else []) + (["-DFVHD_FFN_ABLATE"] if ablate and src == "ffn_fused.hip" else [])
             jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -95,6 +95,43 @@ template <int H> FVHD_DEV void gelu_half(GeluSt& g, f32x2 x, f32x2& out)
 #endif
 }
 
+// Half-precision form (round 3): the kernels are POWER-limited (1.39 kW of the 1.4-kW package cap at C = 96 / 192, 1.31 kW at C = 384:
+// profiles/r03_power_probe.log), so VALU instructions cost wall time even where they hide behind the MFMAs in cycles, and packed-f16
+// VALU does two values per instruction at the price of one scalar f32 one (tools/ubench/f16_rate.hip: the chunk loop without its LDS
+// side 508 -> 467 us per 1000 chunks at C = 192, 348 -> 294 at C = 96).  Measured on the kernel, sustained: 481 -> 450 us at C = 96,
+// 357 -> 336 at C = 192, 339 -> 336 at C = 384 (profiles/r03_ffn_f16.log).  GEMM1 delivers x' = x / 4 (W1 and b1 pre-scaled by 1/4 - exact; b1 rides in the accumulator), so that every coefficient
+// of   Phi(x) = clamp01(0.5 + x' Q'(min(x'^2, (3.5/4)^2)))   is O(1..10) in f16;  y' = x' Phi = gelu(x) / 4 is the f16 B operand of GEMM2
+// (v_mfma_f32_32x32x16_f16) as it stands, W2 packed as f16(4 W2).  11 packed instructions per PAIR: cvt (round toward zero: saturates at
+// |x| = 262016 instead of overflowing), mul, min, 5 fma, fma + clamp modifier, mul.  Accuracy of the hidden activation against the exact
+// erf GELU (tools/ubench/g16.py): relative 0.5-1.0e-3, against 1.7e-3 for f32 math + rounding to bf16 - P now carries 11 mantissa bits
+// instead of 8; |Phi error| <= 1.4e-3, Phi(>= 3.5) = 1 and Phi(<= -3.5) = 0 exactly (c0 is nudged one ulp up for that).
+#ifndef FVHD_FFN_F16
+#define FVHD_FFN_F16 2               // 2: every C;  1: C <= 192 only;  0: the f32 GELU + bf16 GEMM2 of rounds 1-2   (A/B builds: -DFVHD_FFN_F16=0)
+#endif
+template <int C> __host__ __device__ constexpr bool ffn_f16() { return FVHD_FFN_F16 == 2 || (FVHD_FFN_F16 == 1 && C <= 192); }
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct GeluSt16 { f16x2 x, u, q; };
+#define FFN_H2(bits) (__builtin_bit_cast(f16x2, (unsigned)(bits) * 0x10001u))
+template <int H> FVHD_DEV void gelu_half16(GeluSt16& g, f32x2 x, f16x2& out)
+{
+    // c_k' = 4 * 16^k * FVHD_GELU5_Ck rounded to f16 (c0' + 1 ulp):  1.5927734375, -4.12109375, 8.703125, -11.7890625, 8.9375, -2.84375
+    if constexpr (H == 0) g.x = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+    else if constexpr (H == 1) {
+        g.u = __builtin_elementwise_min(g.x * g.x, FFN_H2(0x3a20));          // (3.5 / 4)^2 = 0.765625
+        g.q = __builtin_elementwise_fma(FFN_H2(0xc1b0), g.u, FFN_H2(0x4878));
+    } else if constexpr (H == 2) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0xc9e5));
+    else if constexpr (H == 3) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0x485a));
+    else if constexpr (H == 4) {
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0xc41f));
+        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0x3e5f));
+    } else {
+        f16x2 phi;
+        asm("v_pk_fma_f16 %0, %1, %2, %3 clamp" : "=v"(phi) : "v"(g.x), "v"(g.q), "v"(FFN_H2(0x3800)));
+        out = g.x * phi;
+    }
+}
+
 // 16 B/lane LDS-DMA (global -> LDS, no VGPR staging): LDS destination = wave-uniform byte address `lds_dst` + lane*16.
 // Issued from inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc's waitcnt pass
 // degrades every counted lgkmcnt(N) of the fragment ds_reads to lgkmcnt(0) (measured: 96 counted waits without the
@@ -112,7 +149,7 @@ FVHD_DEV void ffn_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); 
 //                (some slots) | 96*NB/NM GELU half-stages (2-3 VALU each, from independent dependency chains) }
 // i.e. every 32-cycle MFMA carries a handful of independent single-issue fillers - what one wave can issue in its shadow
 // (MI355X_MICROARCH "one wave per SIMD") - instead of 200+ VALU in a lump between two MFMA bursts.
-template <int C, int NB, int WAVES, bool DO_A, bool DO_B, bool DO_C, bool DO_DMA, int VAR, int PF, bool BPRE = (C == 96)>
+template <int C, int NB, int WAVES, bool DO_A, bool DO_B, bool DO_C, bool DO_DMA, int VAR, int PF, bool F16 = ffn_f16<C>(), bool BPRE = (C == 96 || F16)>
 FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32], f32x16 (&s_out)[NB], const f32x16 (&s_in)[NB],
                        bf16x8 (&p_out)[NB][2], const bf16x8 (&p_in)[NB][2], const char* const (&w1p)[C / 48],
                        const char* const (&w2p)[2], const int ring, const float* b1_cur, const float* b1_prev, int half,
@@ -137,6 +174,8 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
     f32x4 bv[4];
     GeluSt gs[NB][8];
     f32x2 gout[NB][8];
+    GeluSt16 gs16[NB][8];
+    f16x2 gout16[NB][8];
     // b1: either the GEMM1 accumulator starts from it (BPRE: 16 more live registers at the top of the iteration, no VALU), or
     // it is added in the first GELU half-stage (value r <-> hidden (r&3) + 8(r>>2) + 4*half)
     if constexpr (DO_A && BPRE) {
@@ -166,6 +205,8 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
             if constexpr (DO_C) {
                 const int g = f >> 1;
                 if constexpr (VAR & 4) asm volatile("" ::"v"(wf[f]), "v"(p_in[nb][g & 1]));   // ablation: no GEMM2 MFMA
+                else if constexpr (F16)
+                    o[nb][g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[f]), __builtin_bit_cast(f16x8, p_in[nb][g & 1]), o[nb][g >> 1], 0, 0, 0);
                 else o[nb][g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f], p_in[nb][g & 1], o[nb][g >> 1], 0, 0, 0);
             }
         }
@@ -190,8 +231,27 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
             }
 #pragma unroll
             for (int u = m * UPS / 2; u < (m + 1) * UPS / 2; ++u) {     // unit u = ((pair j, half-stage h), block gb)
-                const int gb = u % NB, jh = u / NB, h = jh % 6, r = 2 * (jh / 6);
+                // f32 form: one pair at a time (register budget at C = 384); f16 form: two pairs in flight with their half-stages
+                // alternating, so that consecutive packed instructions are independent (a dependent pair costs an s_nop each)
+                const int gb = u % NB, jh = u / NB, h = F16 ? (jh % 12) / 2 : jh % 6, r = F16 ? 2 * (2 * (jh / 12) + (jh & 1)) : 2 * (jh / 6);
                 f32x2 sv = {s_in[gb][r], s_in[gb][r + 1]};
+                if constexpr (F16) {         // b1 / 4 came in through the accumulator (BPRE)
+                    if (VAR & 2) {
+                        if (h == 5) gout16[gb][r >> 1] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(sv[0], sv[1]));
+                    } else if (h == 0) gelu_half16<0>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                    else if (h == 1) gelu_half16<1>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                    else if (h == 2) gelu_half16<2>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                    else if (h == 3) gelu_half16<3>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                    else if (h == 4) gelu_half16<4>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                    else gelu_half16<5>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                    if (h == 5) {
+                        f16x8 pt = __builtin_bit_cast(f16x8, p_out[gb][r >> 3]);
+                        pt[r & 7] = gout16[gb][r >> 1][0];
+                        pt[(r & 7) + 1] = gout16[gb][r >> 1][1];
+                        p_out[gb][r >> 3] = __builtin_bit_cast(bf16x8, pt);
+                    }
+                    continue;
+                }
                 if (!BPRE && (h == 0 || ((VAR & (2 | 64)) && h == 5))) sv += f32x2{bv[r >> 2][r & 3], bv[r >> 2][(r & 3) + 1]};
                 if (VAR & 2) {               // ablation bit 1: no GELU math
                     if (h == 5) gout[gb][r >> 1] = sv;
@@ -264,7 +324,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     const int uwave = __builtin_amdgcn_readfirstlane(wave);          // provably uniform: DMA bases stay in SGPRs / M0
     const unsigned lds_w1 = __builtin_amdgcn_readfirstlane(lds_addr(w1ring)), lds_w2 = __builtin_amdgcn_readfirstlane(lds_addr(w2ring));
 
-    for (int i = tid; i < HID / 4; i += WAVES * 64) *(f32x4*)&lb1[i * 4] = *(const f32x4*)&b1[i * 4];
+    for (int i = tid; i < HID / 4; i += WAVES * 64)
+        *(f32x4*)&lb1[i * 4] = *(const f32x4*)&b1[i * 4] * (ffn_f16<C>() ? 0.25f : 1.0f);          // half-precision form: GEMM1 delivers x / 4
 
     // per-lane fragment pointers (ring slot 0), see ffn_iter
     const char* w1p[C / 48];
@@ -477,9 +538,31 @@ static uint16_t to_bf16(float f)      // round-to-nearest-even, as torch's .to(b
     return (uint16_t)(u >> 16);
 }
 
+static uint16_t to_f16(float f)       // round-to-nearest-even, subnormals kept, saturating at +-65504 (a weight never gets there)
+{
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);                // >= 65520 rounds past the largest finite: saturate
+    if (a < 0x33000001u) return sign;                                       // < 2^-25 (or the tie at 2^-25) -> 0
+    const int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                               // 24-bit significand
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                             // normal: keep 11 bits; subnormal: fewer
+    const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
+    m >>= shift;
+    if (rest > half || (rest == half && (m & 1u))) ++m;
+    const uint32_t bits = e >= -14 ? (uint32_t)((e + 15 - 1) << 10) + m : m;   // the hidden bit of m carries into the exponent field
+    return (uint16_t)(sign | bits);
+}
+
 extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uint16_t* w1img, uint16_t* w2img)
 {
     if (!fvhd_ffn_fused_supported(C)) return 1;
+    // half-precision form (see gelu_half16): W1 carries the factor 1/4 (exact in bf16), W2 is f16(4 W2)
+    const bool f16 = C == 384 ? ffn_f16<384>() : C == 192 ? ffn_f16<192>() : ffn_f16<96>();
+    const float s1 = f16 ? 0.25f : 1.0f;
     const int HID = 4 * C, NCH = HID / 32, CHE = 32 * C;   // bf16 elements per chunk image
     for (int i = 0; i < (NCH + 1) * CHE; ++i) w1img[i] = 0;
     for (int ch = 0; ch < NCH; ++ch) {
@@ -488,7 +571,7 @@ extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uin
         for (int row = 0; row < 32; ++row)
             for (int slot = 0; slot < C / 8; ++slot) {
                 const int off = (C == 384 ? w1_off<384>(row, slot) : C == 192 ? w1_off<192>(row, slot) : w1_off<96>(row, slot)) / 2;
-                for (int e = 0; e < 8; ++e) i1[off + e] = to_bf16(fc1[(size_t)(ch * 32 + row) * C + slot * 8 + e]);
+                for (int e = 0; e < 8; ++e) i1[off + e] = to_bf16(s1 * fc1[(size_t)(ch * 32 + row) * C + slot * 8 + e]);
             }
         for (int n = 0; n < C; ++n)
             for (int slot = 0; slot < 4; ++slot) {
@@ -496,7 +579,8 @@ extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uin
                 for (int e = 0; e < 8; ++e) {
                     const int pos = slot * 8 + e, kb = pos >> 4, hf = (pos >> 3) & 1, j = pos & 7;
                     const int h = 16 * kb + 8 * (j >> 2) + 4 * hf + (j & 3);
-                    i2[off + e] = to_bf16(fc2[(size_t)n * HID + ch * 32 + h]);
+                    const float w = fc2[(size_t)n * HID + ch * 32 + h];
+                    i2[off + e] = f16 ? to_f16(4.0f * w) : to_bf16(w);
                 }
             }
     }
