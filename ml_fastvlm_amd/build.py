@@ -32,8 +32,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # (tools/ubench/f16_rate.hip "shadow"); bit-identical results, -1 % on the fused FFN, -2 % on attention (profiles/r03_nopk_ab.log).
 # (the host pass prints "'-packed-fp32-ops' is not a recognized feature for this target": it is a device feature, harmless)
 NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+# -amdgpu-mfma-vgpr-form (round 3): MFMA accumulators in VGPRs.  By default hipcc puts them in AGPRs and shuttles every value the VALU
+# touches through v_accvgpr_read / _write (8 cycles each, tools/ubench/f16_rate.hip): 144 of ~450 VALU instructions per key tile of
+# the attention kernel.  Bit-identical results; attention 1.23 -> 1.02 ms per step, stem -2 %, the prefill attention -0.1 ms of TTFT
+# (profiles/r03_vgpr_form_ab.log).  Not for ffn_fused.hip (C = 384 needs all 512 registers) nor gemm.hip (neutral).
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"] + NOPK,
-               "attention.hip": NOPK, "llm.hip": NOPK,
+               "attention.hip": NOPK + VGPR_FORM, "llm.hip": NOPK + VGPR_FORM, "stem_head.hip": VGPR_FORM,
                # dwconv_mfma.hip: 7 x 84 hand-placed MFMA slots, every register-array index compile-time (768 B/lane of scratch otherwise)
                "dwconv_mfma.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 

@@ -138,11 +138,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 
     const int ntiles = (N + ATT_KT - 1) / ATT_KT;
     u32x4 rk, rv;
-    {
-        const int key = min(skey, N - 1);
-        rk = *(const u32x4*)(kptr + (size_t)key * row_stride);
-        rv = *(const u32x4*)(vptr + (size_t)key * row_stride);
-    }
+    // running pointers of this thread's K / V rows: one 64-bit add per tile instead of a 64-bit multiply; only a tile that reaches
+    // past N clamps its key index (a wave-uniform branch)
+    const bf16* kcur = kptr + (size_t)min(skey, N - 1) * row_stride;
+    const bf16* vcur = vptr + (size_t)min(skey, N - 1) * row_stride;
+    const size_t tile_step = (size_t)ATT_KT * row_stride;
+    rk = *(const u32x4*)kcur;
+    rv = *(const u32x4*)vcur;
     for (int t = 0; t < ntiles; ++t) {
         char* kbuf = lds + (t & 1) * (ATT_KT * 64 + ATT_D * ATT_VT_STRIDE);
         char* vbuf = kbuf + ATT_KT * 64;
@@ -154,9 +156,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
         }
         __syncthreads();
         if (t + 1 < ntiles) {
-            const int key = min((t + 1) * ATT_KT + skey, N - 1);
-            rk = *(const u32x4*)(kptr + (size_t)key * row_stride);
-            rv = *(const u32x4*)(vptr + (size_t)key * row_stride);
+            if ((t + 2) * ATT_KT <= N) {
+                kcur += tile_step;
+                vcur += tile_step;
+            } else {
+                const int key = min((t + 1) * ATT_KT + skey, N - 1);
+                kcur = kptr + (size_t)key * row_stride;
+                vcur = vptr + (size_t)key * row_stride;
+            }
+            rk = *(const u32x4*)kcur;
+            rv = *(const u32x4*)vcur;
         }
 
         // S^T[key][q] for 4 key fragments of 16: one K fragment read per fragment, used by every query block
@@ -169,7 +178,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             for (int w = 0; w < ATT_QW; ++w)
                 s[w][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[w], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        const bool ragged = (t + 1) * ATT_KT > N;
+        if ((t + 1) * ATT_KT > N) {
+            // the one tile that reaches past N (none when N % 64 == 0): a REAL wave-uniform branch - as selects inside the loop below
+            // the masking cost 3 VALU instructions per score on every tile (the asm statement keeps the block from being if-converted)
+            asm volatile("; ragged key tile");
+#pragma unroll
+            for (int w = 0; w < ATT_QW; ++w)
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * ATT_KT + kf * 16 + g * 4 + r >= N) s[w][kf][r] = -1e30f;
+        }
         bf16x8 pf[ATT_QW][2];   // B operand of O^T = V^T . P^T: n = q = lr, k-slot j <-> key (j<4 ? 4g+j : 16+4g+j-4) of chunk c
 #pragma unroll
         for (int w = 0; w < ATT_QW; ++w) {
@@ -177,10 +197,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (ragged && t * ATT_KT + kf * 16 + g * 4 + r >= N) s[w][kf][r] = -1e30f;
-                    mx = fmaxf(mx, s[w][kf][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[w][kf][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[w], mx);

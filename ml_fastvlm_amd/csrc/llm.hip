@@ -221,6 +221,23 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
                 for (int w = 0; w < K::QW; ++w) s[w][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[w][kk], s[w][kf], 0, 0, 0);
             }
         }
+        // masking only where a tile needs it - a padded key in it, or keys beyond the wave's FIRST query (the causal diagonal): a real
+        // wave-uniform branch (as selects in the loop below the mask cost ~3 VALU instructions per score on every tile; the asm
+        // statement keeps the block from being if-converted)
+        const int q_first = qb * K::QB + wave * K::QW * 16;
+        if (vmask != ~0ull || t * K::KT + K::KT - 1 > q_first) {
+            asm volatile("; masked key tile");
+#pragma unroll
+            for (int w = 0; w < K::QW; ++w)
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kin = kf * 16 + g * 4 + r;                    // key inside the tile
+                        const bool ok = ((vmask >> kin) & 1ull) && (t * K::KT + kin <= q_idx[w]);
+                        if (!ok) s[w][kf][r] = -1e30f;
+                    }
+        }
         bf16x8 pf[K::QW][2];
 #pragma unroll
         for (int w = 0; w < K::QW; ++w) {
@@ -228,12 +245,7 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kin = kf * 16 + g * 4 + r;                    // key inside the tile
-                    const bool ok = ((vmask >> kin) & 1ull) && (t * K::KT + kin <= q_idx[w]);
-                    if (!ok) s[w][kf][r] = -1e30f;
-                    mx = fmaxf(mx, s[w][kf][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[w][kf][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[w], mx);

@@ -112,6 +112,31 @@ def dw7():
     return (lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 7, 1, 1, 0))), 2.0 * y.numel() * 49, (x, y, w, bias)
 
 
+def attn():
+    B, N, Cc = 32, 1024, 768
+    qkv = torch.randn(B * N, 3 * Cc).to(DEV, torch.bfloat16)
+    out = torch.empty(B * N, Cc, device=DEV, dtype=torch.bfloat16)
+    return (lambda: _lib.check(lib.fvhd_op_attention(stream(), p(qkv), p(out), B, N, Cc))), 4.0 * B * (Cc // 32) * N * N * 32, (qkv, out)
+
+
+def dw3():
+    B, H, Cc = 32, 128, 192
+    x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+    y = torch.empty_like(x)
+    w = torch.randn(9, Cc, device=DEV)
+    bias = torch.randn(Cc, device=DEV)
+    return (lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 3, 1, 1, 0))), 2.0 * y.numel() * 9, (x, y, w, bias)
+
+
+def stem():
+    B, R = 32, 1024
+    img = torch.rand(B, 3, R, R).to(DEV, torch.bfloat16)
+    w0, b0 = (torch.randn(27, 96) * 0.3).to(DEV), (torch.randn(96) * 0.1).to(DEV)
+    w1, b1 = (torch.randn(9, 96) * 0.3).to(DEV), (torch.randn(96) * 0.1).to(DEV)
+    out = torch.empty(B, R // 4, R // 4, 96, dtype=torch.bfloat16, device=DEV)
+    return (lambda: _lib.check(lib.fvhd_op_stem_fused(stream(), p(img), 2, p(out), p(w0), p(b0), p(w1), p(b1), B, R))), 2.0 * B * (R // 2) ** 2 * 96 * 27, (img, w0, b0, w1, b1, out)
+
+
 def run(name, seconds=3.0):
     if name == "idle":
         fn, flops, keep = (lambda: None), 0.0, None
@@ -119,6 +144,8 @@ def run(name, seconds=3.0):
         fn, flops, keep = ffn(int(name[3:]))
     elif name == "gemm":
         fn, flops, keep = gemm()
+    elif name in ("attn", "dw3", "stem"):
+        fn, flops, keep = {"attn": attn, "dw3": dw3, "stem": stem}[name]()
     else:
         fn, flops, keep = dw7()
     for _ in range(5):
