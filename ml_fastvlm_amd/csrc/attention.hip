@@ -219,9 +219,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             }
             psum += __shfl_xor(psum, 16, 64);
             psum += __shfl_xor(psum, 32, 64);
-            l_run[w] = l_run[w] * alpha + psum;
-            o_acc[w][0] *= alpha;
-            o_acc[w][1] *= alpha;
+            // after the first tiles the running maximum rarely moves: alpha == 1 exactly (exp2(0)), and multiplying by it is the
+            // identity - skipped when no lane of the wave saw a new maximum (same bits, 10 VALU instructions fewer per tile)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+                l_run[w] *= alpha;
+                o_acc[w][0] *= alpha;
+                o_acc[w][1] *= alpha;
+            }
+            l_run[w] += psum;
         }
 #pragma unroll
         for (int df = 0; df < 2; ++df)

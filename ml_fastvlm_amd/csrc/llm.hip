@@ -272,9 +272,12 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
             }
             psum += __shfl_xor(psum, 16, 64);
             psum += __shfl_xor(psum, 32, 64);
-            l_run[w] = l_run[w] * alpha + psum;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // alpha == 1 exactly once the running maximum stops moving
+                l_run[w] *= alpha;
 #pragma unroll
-            for (int df = 0; df < DF; ++df) o_acc[w][df] *= alpha;
+                for (int df = 0; df < DF; ++df) o_acc[w][df] *= alpha;
+            }
+            l_run[w] += psum;
         }
 #pragma unroll
         for (int df = 0; df < DF; ++df)
