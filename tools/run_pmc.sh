@@ -19,7 +19,7 @@ run trace
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run sq --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS
-run grbm --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+run grbm --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 python tools/pmc_summary.py ${TAG} gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_sq gpurun_out/${TAG}_grbm > gpurun_out/${TAG}_pmc_summary.md
 cp profiles/${TAG}_pmc_summary.json gpurun_out/ 2>/dev/null
 python tools/rocpd_summary.py gpurun_out/${TAG}_trace/trace_results.db > gpurun_out/${TAG}_kernel_trace_stats_single_stream.md
