@@ -21,7 +21,7 @@
 //     already a valid B operand of O^T = V^T . P^T for a permuted key order - the same permutation
 //     the V^T fragment is read with - so P never leaves registers.
 //   * online softmax in fp32 with exp2 (scale * log2 e folded), P rounded to bf16 for the MFMA,
-//     row sums accumulated from the fp32 values, O^T accumulators fp32; out-of-range keys are
+//     row sums of those bf16 values accumulated in fp32 by the matrix cores (a ones fragment), O^T accumulators fp32; out-of-range keys are
 //     masked to -1e30, out-of-range queries are not stored (any N works, e.g. 16 or 576).
 #include "fvhd_common.h"
 
@@ -127,13 +127,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const int k_dst = skey * 64 + ((sch ^ ((0 - (skey >> 2)) & 3)) << 4);
 
     f32x4 o_acc[ATT_QW][2];                              // O^T[d = df*16 + 4g + r][q = lr]
-    float m_run[ATT_QW], l_run[ATT_QW];
+    // softmax denominators on the matrix cores: a third "V^T fragment" of ones makes every row of l_acc the sum over the keys of the
+    // SAME bf16 P values that multiply V (fp32 accumulate) - 2 more MFMAs per query block and tile instead of 16 v_add_f32 + 2
+    // cross-lane shuffles + their waits (the kernel is VALU-bound: ~170 VALU instructions per 16 MFMAs)
+    f32x4 l_acc[ATT_QW];
+    float m_run[ATT_QW];
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 #pragma unroll
     for (int w = 0; w < ATT_QW; ++w) {
         o_acc[w][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         o_acc[w][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        l_acc[w] = f32x4{0.f, 0.f, 0.f, 0.f};
         m_run[w] = -1e30f;
-        l_run[w] = 0.f;
     }
 
     const int ntiles = (N + ATT_KT - 1) / ATT_KT;
@@ -204,7 +211,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             const float alpha = __builtin_amdgcn_exp2f((m_run[w] - m_new) * scale_log2e);
             m_run[w] = m_new;
             const float mb = m_new * scale_log2e;
-            float psum = 0.f;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 f32x8 p;
@@ -213,20 +219,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                     p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c][r], scale_log2e, -mb));
                     p[4 + r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c + 1][r], scale_log2e, -mb));
                 }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) psum += p[r];
                 pf[w][c] = f32_to_bf8(p);
             }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
             // after the first tiles the running maximum rarely moves: alpha == 1 exactly (exp2(0)), and multiplying by it is the
-            // identity - skipped when no lane of the wave saw a new maximum (same bits, 10 VALU instructions fewer per tile)
+            // identity - skipped when no lane of the wave saw a new maximum (same bits, 12 VALU instructions fewer per tile)
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-                l_run[w] *= alpha;
+                l_acc[w] *= alpha;
                 o_acc[w][0] *= alpha;
                 o_acc[w][1] *= alpha;
             }
-            l_run[w] += psum;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) l_acc[w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[w][c], l_acc[w], 0, 0, 0);
         }
 #pragma unroll
         for (int df = 0; df < 2; ++df)
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 #pragma unroll
     for (int w = 0; w < ATT_QW; ++w)
         if (q_idx[w] < N) {
-            const float inv = 1.0f / l_run[w];
+            const float inv = 1.0f / l_acc[w][0];
             bf16* orow = out + ((size_t)b * N + q_idx[w]) * C + h * ATT_D;
 #pragma unroll
             for (int df = 0; df < 2; ++df)

@@ -166,13 +166,17 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
     }
 
     f32x4 o_acc[K::QW][DF];
-    float m_run[K::QW], l_run[K::QW];
+    f32x4 l_acc[K::QW];                 // softmax denominators on the matrix cores (a ones fragment as one more V^T fragment: attention.hip)
+    float m_run[K::QW];
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 #pragma unroll
     for (int w = 0; w < K::QW; ++w) {
 #pragma unroll
         for (int df = 0; df < DF; ++df) o_acc[w][df] = f32x4{0.f, 0.f, 0.f, 0.f};
+        l_acc[w] = f32x4{0.f, 0.f, 0.f, 0.f};
         m_run[w] = -1e30f;
-        l_run[w] = 0.f;
     }
 
     const int kmax = min(T, (qb + 1) * K::QB);                  // causal: no key beyond this workgroup's last query
@@ -257,7 +261,6 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
             const float alpha = __builtin_amdgcn_exp2f((m_run[w] <= -1e29f ? -1e30f : m_run[w] - m_ref) * scale_log2e);
             m_run[w] = m_new;
             const float mb = m_ref * scale_log2e;
-            float psum = 0.f;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 f32x8 p;
@@ -266,18 +269,15 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
                     p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c][r], scale_log2e, -mb));
                     p[4 + r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c + 1][r], scale_log2e, -mb));
                 }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) psum += p[r];
                 pf[w][c] = f32_to_bf8(p);
             }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // alpha == 1 exactly once the running maximum stops moving
-                l_run[w] *= alpha;
+                l_acc[w] *= alpha;
 #pragma unroll
                 for (int df = 0; df < DF; ++df) o_acc[w][df] *= alpha;
             }
-            l_run[w] += psum;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) l_acc[w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[w][c], l_acc[w], 0, 0, 0);
         }
 #pragma unroll
         for (int df = 0; df < DF; ++df)
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void llm_attention_kernel(const bf16* __restri
         if (q_idx[w] < T) {
             // a query row whose keys are ALL masked (a padding position in front of a left-padded sequence) has l = 0: it is written
             // as zeros - finite, and never read (the reference produces equally meaningless rows there)
-            const float inv = l_run[w] > 0.f ? 1.0f / l_run[w] : 0.f;
+            const float inv = l_acc[w][0] > 0.f ? 1.0f / l_acc[w][0] : 0.f;
             bf16* orow = out + ((size_t)b * T + q_idx[w]) * ((size_t)nh * HD) + h * HD;
 #pragma unroll
             for (int df = 0; df < DF; ++df) *(bf16x4*)(orow + df * 16 + g * 4) = f32_to_bf4(o_acc[w][df] * inv);
