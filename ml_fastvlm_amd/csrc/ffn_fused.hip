@@ -104,7 +104,8 @@ template <int H> FVHD_DEV void gelu_half(GeluSt& g, f32x2 x, f32x2& out)
 // (v_mfma_f32_32x32x16_f16) as it stands, W2 packed as f16(4 W2).  11 packed instructions per PAIR: cvt (round toward zero: saturates at
 // |x| = 262016 instead of overflowing), mul, min, 5 fma, fma + clamp modifier, mul.  Accuracy of the hidden activation against the exact
 // erf GELU (tools/ubench/g16.py): relative 0.5-1.0e-3, against 1.7e-3 for f32 math + rounding to bf16 - P now carries 11 mantissa bits
-// instead of 8; |Phi error| <= 1.4e-3, Phi(>= 3.5) = 1 and Phi(<= -3.5) = 0 exactly (c0 is nudged one ulp up for that).
+// instead of 8; |Phi error| <= 1.4e-3; Phi = 1 exactly from x = 3.5 on and 0 exactly below -3.51 (c0 is nudged one ulp up for that; at -3.5
+// itself the half-precision sum leaves 2^-13 against the true 2.3e-4) - tests/test_gelu_f16.py restates the sequence in numpy.
 #ifndef FVHD_FFN_F16
 #define FVHD_FFN_F16 2               // 2: every C;  1: C <= 192 only;  0: the f32 GELU + bf16 GEMM2 of rounds 1-2   (A/B builds: -DFVHD_FFN_F16=0)
 #endif
