@@ -192,9 +192,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // MFMAs instead of 8 per 16 (the LDS pipe was the co-bottleneck of v2), 128 accumulator registers per lane, two 64-KB stages (128 KB:
 // one workgroup per CU, two waves per SIMD) - the "256^2 tile, glds, 2 LDS buffers, BK = 64, vmcnt(0) + barrier" structure of
 // cdna_hip_programming.md 5.  Taken when N % 256 == 0 and there are at least two rounds of tiles.
-template <int BN> struct G2Cfg {
-    static constexpr int RS = BN == 256 ? 2 : 3, STAGE = (256 + BN) * 128, LDS = RS * STAGE;
+template <int BN, int BK = 64> struct G2Cfg {
+    static constexpr int RS = BN == 256 ? 2 : 3, STAGE = (256 + BN) * BK * 2, LDS = RS * STAGE;
 };
+// the XOR key of lds_off<BK> as a function of the row (the LDS-DMA applies it on the global side)
+template <int BK> FVHD_DEV int lds_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); }
 
 FVHD_DEV void glds_piece(unsigned voff, const void* sbase, unsigned m0v)
 {
@@ -203,15 +205,18 @@ FVHD_DEV void glds_piece(unsigned voff, const void* sbase, unsigned m0v)
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0v) : "memory");
 }
 
-template <int EPI, int ODT, int NWV, int BN = 128>
-__global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
+// BKT = 32 (debug-build experiment, knob 5): K tiles of 32 in a 3-stage ring = 72 KB at BN = 128, so that TWO 4-wave workgroups share a CU
+// and one's prologue / epilogue runs behind the other's MFMAs; pieces are then 16 rows x 64 B.
+template <int EPI, int ODT, int NWV, int BN = 128, int BKT = 64>
+__global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gemm256_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ ls, const bf16* resid, void* out, int M, int N, int K, int tiles_n, int nwg)
 {
     // BN = 128, NWV = 8: waves 4 (M) x 2 (N), 64 x 64 each (two per SIMD).  BN = 128, NWV = 4: 2 x 2, 128 x 64 each - 12 instead of 16 fragment
     // reads per 32 MFMAs, one wave per SIMD.  BN = 256, NWV = 8: 2 x 4, 128 x 64 each, two per SIMD.
-    constexpr int BM = 256, BK = 64, WN = BN / 64, WM = NWV / WN, MF = BM / WM / 16, NF = 4, RS = G2Cfg<BN>::RS, STAGE = G2Cfg<BN>::STAGE;
-    constexpr int PA = 32 / NWV, PW = (BN / 8) / NWV;         // 1-KiB pieces (8 rows x 128 B) of the A / W tile per wave
+    constexpr int BM = 256, BK = BKT, WN = BN / 64, WM = NWV / WN, MF = BM / WM / 16, NF = 4, RS = G2Cfg<BN, BK>::RS, STAGE = G2Cfg<BN, BK>::STAGE;
+    constexpr int RPP = 1024 / (BK * 2), LPR = BK / 8;        // rows per 1-KiB piece (8 / 16), lanes (16-B chunks) per row (8 / 4)
+    constexpr int PA = (BM / RPP) / NWV, PW = (BN / RPP) / NWV;   // 1-KiB pieces of the A / W tile per wave
     static_assert(WM * WN == NWV && MF * 16 * WM == BM, "wave grid");
     extern __shared__ __attribute__((aligned(16))) char lds2[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,24 +232,24 @@ __global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
 
     // per-lane global byte offsets of this wave's pieces: rows 8 p + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7); the swizzle
     // term depends on the piece's parity only, the row base of a piece goes into the scalar base
-    const int rip = lane >> 3;
+    const int rip = lane / LPR;
     unsigned va[2], vw[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-        const int sw = ((par * 8 + rip) >> 1) & 7;
-        va[par] = (unsigned)((rip * K + (((lane & 7) ^ sw) * 8)) * 2);
+        const int sw = lds_swz<BK>(par * RPP + rip);
+        va[par] = (unsigned)((rip * K + (((lane % LPR) ^ sw) * 8)) * 2);
         vw[par] = va[par];
     }
-    const char* abase = (const char*)(A + (size_t)(m0 + wave * 8 * PA) * K);   // A pieces PA wave .. PA wave + PA - 1 = rows 8 PA wave ..
-    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * 8 * PW) * K);  // W pieces PW wave ..
+    const char* abase = (const char*)(A + (size_t)(m0 + wave * RPP * PA) * K);   // A pieces PA wave .. PA wave + PA - 1 = rows RPP PA wave ..
+    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * RPP * PW) * K);  // W pieces PW wave ..
     const unsigned lds0 = lds_addr(lds2);
     auto issue = [&](int kt) {
         const unsigned st = lds0 + (kt % RS) * STAGE;
         const size_t ko = (size_t)kt * BK * 2;
 #pragma unroll
-        for (int j = 0; j < PA; ++j) glds_piece(va[(wave * PA + j) & 1], abase + (size_t)j * 8 * K * 2 + ko, st + (wave * PA + j) * 1024);
+        for (int j = 0; j < PA; ++j) glds_piece(va[(wave * PA + j) & 1], abase + (size_t)j * RPP * K * 2 + ko, st + (wave * PA + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < PW; ++j) glds_piece(vw[(wave * PW + j) & 1], wbase + (size_t)j * 8 * K * 2 + ko, st + 256 * 128 + (wave * PW + j) * 1024);
+        for (int j = 0; j < PW; ++j) glds_piece(vw[(wave * PW + j) & 1], wbase + (size_t)j * RPP * K * 2 + ko, st + BM * BK * 2 + (wave * PW + j) * 1024);
     };
 
     f32x4 acc[MF][NF];
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(64 * NWV) void gemm256_kernel(
         __syncthreads();                              // tile kt visible to every wave; tile kt - 1 fully consumed
         if (kt + RS - 1 < nk) issue(kt + RS - 1);     // into the stage tile kt - 1 occupied
         const char* ldsA = lds2 + (kt % RS) * STAGE;
-        const char* ldsW = ldsA + 256 * 128;
+        const char* ldsW = ldsA + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 af[MF], wf[NF];
@@ -402,7 +407,7 @@ extern "C" void fvhd_debug_set_gemm_v2(int on) { g_gemm_v2 = on; }
 static constexpr int g_gemm_v2 = 1;
 #endif
 
-template <int EPI, int ODT, int NWV, int BN = 128>
+template <int EPI, int ODT, int NWV, int BN = 128, int BKT = 64>
 static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
                                  const bf16* resid, void* out, int M, int N, int K)
 {
@@ -410,12 +415,13 @@ static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<BN>::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV, BN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<BN, BKT>::LDS);
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = true;
     }
     const int tiles_m = M / 256, tiles_n = N / BN, nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN>), dim3(nwg), dim3(64 * NWV), G2Cfg<BN>::LDS, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+    constexpr int LDSB = G2Cfg<BN, BKT>::LDS;
+    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN, BKT>), dim3(nwg), dim3(64 * NWV), LDSB, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
     return hipGetLastError();
 }
 
@@ -465,6 +471,23 @@ static hipError_t dispatch_gemm256(hipStream_t st, const bf16* a, const bf16* w,
     }
     return hipErrorInvalidValue;
 }
+
+#ifdef FVHD_DEBUG_KNOBS
+// knob 5 (experiment, debug library only): 256 x 128 tile, 4 waves of 128 x 64, K tiles of 32 in a 72-KB ring -> two workgroups per CU
+static hipError_t dispatch_gemm256_2wg(hipStream_t st, const bf16* a, const bf16* w, const float* bias, const float* ls, const bf16* r, void* out,
+                                       int M, int N, int K, int epi)
+{
+    switch (epi) {
+    case EPI_NONE: return launch_gemm256<EPI_NONE, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS: return launch_gemm256<EPI_BIAS, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_GELU: return launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_LS_RESID: return launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_RESID: return launch_gemm256<EPI_RESID, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_SWIGLU: return launch_gemm256<EPI_SWIGLU, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    }
+    return hipErrorInvalidValue;
+}
+#endif
 
 template <int NF, int BK, int EPI, int ODT>
 static hipError_t launch_gemm(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
@@ -544,9 +567,12 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     // projector fc 68 -> 56; with 384 tiles (stage-5 proj / fc2, 1.5 rounds) v1 stays ahead.  A 4-wave variant with 128 x 64 per
     // wave (fewer fragment reads, one wave per SIMD) was 10-25 % slower: nothing covers the LDS read latency.
     // g_gemm_v2 (debug build): 0 = v1 only, 1 = the rule below, 2 = the 256 x 128 tile wherever it is legal, 3 = the 256 x 256 tile wherever legal,
-    // 4 = the ping-pong 256 x 256 kernel wherever legal
+    // 4 = the ping-pong 256 x 256 kernel wherever legal, 5 = 256 x 128 / 4 waves / BK 32 / two workgroups per CU wherever legal
     if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128) {
         const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
+#ifdef FVHD_DEBUG_KNOBS
+        if (g_gemm_v2 == 5) return (int)dispatch_gemm256_2wg(st, a, w, bias, ls, r, out, M, N, K, epi);
+#endif
         // measured (tools/bench_ops.py gemm, profiles/r03_gemm_tiles.log, B = 32): the 256 x 256 tile wins from N = 2304 on when it has
         // ~2 rounds of tiles - stage-3 qkv 186 -> 165 us, fc1 268 -> 242, stage-4 fc1 224 -> 204, 7B projector 239 / 267 -> 211 / 239 -
         // ties or loses below (N = 768: 64 -> 74 us) and with 1.3 rounds (prefill gate|up, 342 tiles: 59 -> 65).  All three kernels

@@ -170,9 +170,12 @@ def bench_gemm(B=32):
               # Qwen2-0.5B prefill at B = 8 x 285 tokens (padded to 2304 rows): qkv, o_proj, gate|up (SwiGLU epilogue), down
               ("llm qkv", 2304, 1152, 896, 1), ("llm o_proj", 2304, 896, 896, 4), ("llm gate_up", 2304, 9728, 896, 5), ("llm down", 2304, 896, 4864, 4)]
     raw = _knobs()
-    for v2 in (0, 2, 3, 4, 1):
+    names = ('v1 only (128x128, register prefetch)', 'default dispatch', '256x128 LDS-DMA ring wherever legal', '256x256 tile / 2-stage LDS-DMA wherever legal',
+             '256x256 ping-pong (two wave groups one phase apart) wherever legal', '256x128 / 4 waves / BK 32 / two workgroups per CU wherever legal')
+    variants = tuple(int(v) for v in os.environ.get("BENCH_GEMM_VARIANTS", "0,2,3,4,5,1").split(","))
+    for v2 in variants:
       raw.fvhd_debug_set_gemm_v2(v2)
-      print(f"--- gemm: {('v1 only (128x128, register prefetch)', 'default dispatch', '256x128 LDS-DMA ring wherever legal', '256x256 tile / 2-stage LDS-DMA wherever legal', '256x256 ping-pong (two wave groups one phase apart) wherever legal')[v2]}")
+      print(f"--- gemm: {names[v2]}")
       for name, M, N, K, epi in shapes:
         A = torch.randn(M, K).to(DEV, torch.bfloat16)
         W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
@@ -186,14 +189,15 @@ def bench_gemm(B=32):
         bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
         res = torch.randn(M, N).to(DEV, torch.bfloat16)
         outs = []
-        for v2 in (0, 2, 3, 4):
+        for v2 in (0, 2, 3, 4, 5):
             raw.fvhd_debug_set_gemm_v2(v2)
             out = res.clone() if epi != 5 else torch.zeros(M, N // 2, device=DEV, dtype=torch.bfloat16)
             _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(res), p(out), M, N, K, epi, 2))
             torch.cuda.synchronize()
             outs.append(out.float())
         print(f"gemm {name}: v1 vs 256x128 equal {bool(torch.equal(outs[0], outs[1]))}, v1 vs 256x256 equal {bool(torch.equal(outs[0], outs[2]))}, "
-              f"v1 vs ping-pong equal {bool(torch.equal(outs[0], outs[3]))} (max diff {float((outs[0] - outs[3]).abs().max()):.3g})")
+              f"v1 vs ping-pong equal {bool(torch.equal(outs[0], outs[3]))} (max diff {float((outs[0] - outs[3]).abs().max()):.3g}), "
+              f"v1 vs two-workgroup BK 32 equal {bool(torch.equal(outs[0], outs[4]))} (max diff {float((outs[0] - outs[4]).abs().max()):.3g})")
     raw.fvhd_debug_set_gemm_v2(1)
 
 
