@@ -230,8 +230,22 @@ void fvhd_llm_destroy(fvhd_llm* ctx);
  * reference's [out, in] layout; converted (matrices to bf16, vectors to fp32), packed (q|k|v rows concatenated, gate / up rows
  * interleaved) and uploaded before the call returns.  Any other key is an error. */
 int fvhd_llm_set_tensor(fvhd_llm* ctx, const char* key, const void* host_data, int dtype, const int64_t* shape, int ndim);
+/* The same tensor from DEVICE memory on the context's device (a model that already lives on the GPU): matrices must be FVHD_BF16 and
+ * vectors FVHD_F32, row-major contiguous; packed by one device-to-device (2-D) copy on `stream` - no host round trip.  The caller keeps
+ * dev_data alive until `stream` has run the copy. */
+int fvhd_llm_set_tensor_device(fvhd_llm* ctx, const char* key, const void* dev_data, int dtype, const int64_t* shape, int ndim,
+                               fvhd_stream_t stream);
 int fvhd_llm_finalize(fvhd_llm* ctx);                          /* fails if a tensor is missing */
+/* Qwen2Config.max_position_embeddings: rows of the rotary table (default 8192; at most 65536 rows are tabulated).  Position ids beyond
+ * the table are legal: the rotary kernel then computes cos / sin itself with the table's formula - it never clamps.  Takes effect at the
+ * next workspace allocation: call it before fvhd_llm_reserve / the first prefill. */
+int fvhd_llm_set_max_positions(fvhd_llm* ctx, int max_position_embeddings);
 int fvhd_llm_reserve(fvhd_llm* ctx, int batch, int seq_len);   /* size the workspace now (synchronises; not during stream capture) */
+/* Number of times the workspace has been (re)allocated.  A prefill captured into a CALLER's hipGraph holds workspace pointers: the
+ * library never frees a workspace that a capturing stream has used (a later, larger prefill allocates a new one and keeps the old one
+ * alive until fvhd_llm_destroy), so such a graph stays valid; a change of this counter tells the caller that a re-capture would pick up
+ * the new, larger workspace. */
+int fvhd_llm_workspace_generation(const fvhd_llm* ctx);
 /* Prefill: embeds [batch, seq_len, hidden] of `dtype` (the `inputs_embeds` of prepare_inputs_labels_for_multimodal / fvhd_op_splice),
  * key_valid uint8 [batch, seq_len] (its attention mask; NULL = all valid), position_ids int64 [batch, seq_len] (NULL = 0..seq_len-1)
  * -> logits_out fp32 [batch, vocab] of the LAST position of every sequence (what generate() samples the first token from).
@@ -246,10 +260,11 @@ int fvhd_llm_debug_hidden(fvhd_llm* ctx, void* out, int rows, fvhd_stream_t stre
 /* Qwen2RMSNorm: y = w * x * rsqrt(mean(x^2) + eps); x, y [M, H] bf16 (may alias), w fp32 [H], H % 8 == 0 */
 int fvhd_op_rmsnorm(fvhd_stream_t stream, const void* x, void* y, const float* w, int M, int H, float eps);
 /* apply_rotary_pos_emb (rotate_half form) in place on the q and k heads of qkv [M, (n_heads + 2 n_kv_heads) * head_dim] bf16;
- * pos int64 [M] or NULL (row % T); table fp32 [table_positions][head_dim / 2][2] = (cos, sin); k_cache / v_cache as fvhd_llm_prefill
+ * pos int64 [M] or NULL (row % T); table fp32 [table_positions][head_dim / 2][2] = (cos, sin) - a position outside [0, table_positions)
+ * is computed in the kernel from rope_theta (inv_freq_i = theta^(-2i / head_dim), fp32), never clamped; k_cache / v_cache as fvhd_llm_prefill
  * for ONE layer ([M / T][n_kv_heads][T][head_dim]) or NULL */
 int fvhd_op_rope(fvhd_stream_t stream, void* qkv, const int64_t* pos, const float* table, void* k_cache, void* v_cache, int M, int T,
-                 int n_heads, int n_kv_heads, int head_dim, int table_positions);
+                 int n_heads, int n_kv_heads, int head_dim, int table_positions, float rope_theta);
 /* out = resid + A . Wt^T with K split over `splits` workgroups per output tile (Qwen2 down_proj at prefill: few tiles, long K):
  * A [M, K], Wt [N, K], resid [M, N] or NULL (may alias out), out [M, N] bf16; partial: fp32 scratch [splits][M][N]; the slices are
  * summed in order (deterministic) and rounded once.  N % 128 == 0, K % (64 * splits) == 0. */

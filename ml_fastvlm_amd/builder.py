@@ -91,12 +91,13 @@ def encode_images(vision_tower, mm_projector, images):
     return project(vision_tower, mm_projector, image_features)
 
 
-def install_into_llava(splice: bool = False, prefill: bool = False) -> None:
+def install_into_llava(splice: bool = False, prefill: bool = False, prefill_any_dtype: bool = False) -> None:
     """Make an unmodified `llava` package (the reference) build and call the MI355X tower; splice=True also routes
     `prepare_inputs_labels_for_multimodal` through the GPU splice (needs the embeddings on a HIP device); prefill=True also runs the
     PREFILL step of `LlavaQwen2ForCausalLM.forward` (`llava_qwen.py:92-103`: the first forward of `generate`, on `inputs_embeds`
     with an empty cache) on the hand-written Qwen2 kernels (`ml_fastvlm_amd.qwen2_prefill`), handing the KV cache to the stock
-    decode loop."""
+    decode loop.  The kernels compute in bf16: by default only a bf16 model takes them (an fp32 / fp16 model keeps the reference's forward
+    and its precision); prefill_any_dtype=True opts such a model in knowingly (its prefill then runs in bf16, the cache is cast back)."""
     import llava.model.llava_arch as arch
     import llava.model.multimodal_encoder.builder as enc_builder
 
@@ -119,62 +120,82 @@ def install_into_llava(splice: bool = False, prefill: bool = False) -> None:
         arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal = prepare_inputs_labels_for_multimodal
     if prefill:
         import llava.model.language_model.llava_qwen as lq
-        if not getattr(lq.LlavaQwen2ForCausalLM.forward, "_fvhd_prefill", False):
-            lq.LlavaQwen2ForCausalLM.forward = _make_prefill_forward(lq.LlavaQwen2ForCausalLM.forward)
+        cur = lq.LlavaQwen2ForCausalLM.forward
+        lq.LlavaQwen2ForCausalLM.forward = _make_prefill_forward(getattr(cur, "_fvhd_orig", cur), any_dtype=prefill_any_dtype)
 
 
-def _cache_is_empty(pkv) -> bool:
-    if pkv is None:
-        return True
+def _is_fresh_dynamic_cache(pkv) -> bool:
+    """True only for what `generate` hands to its FIRST forward: an empty `transformers.DynamicCache` instance.  `None`, a StaticCache, a
+    legacy tuple or a cache that already holds tokens all mean "not generate's prefill" and keep the reference's forward."""
     try:
-        return pkv.get_seq_length() == 0
+        from transformers import DynamicCache
+        return isinstance(pkv, DynamicCache) and pkv.get_seq_length() == 0
     except Exception:
         return False
 
 
-def _make_prefill_forward(orig_forward):
-    """`LlavaQwen2ForCausalLM.forward` with its prefill step on `fvhd_llm_prefill`.  Taken only where the two are interchangeable:
-    inference (no labels, no grad), a multi-token `inputs_embeds` (given or produced by prepare_inputs_labels_for_multimodal) with an
-    empty cache, on a HIP device, no attention / hidden-state outputs requested; anything else is the reference's own forward.  Returns
-    the logits of the LAST position as [B, 1, vocab] (what `generate` reads: `outputs.logits[:, -1, :]`) and fills the cache."""
+def _make_prefill_forward(orig_forward, any_dtype: bool = False):
+    """`LlavaQwen2ForCausalLM.forward` with its prefill step on `fvhd_llm_prefill`.  The kernel path returns the logits of the LAST
+    position only ([B, 1, vocab] - what `generate` reads: `outputs.logits[:, -1, :]`), computes in bf16 and fills a DynamicCache, so it is
+    taken only where the caller is demonstrably `generate`'s first step (advisor, round 3: a plain scoring forward under no_grad must keep
+    its [B, T, vocab] logits): `use_cache` true AND `past_key_values` an EMPTY `DynamicCache` instance (generate creates it before the first
+    forward; a bare `model(...)` call passes None), a bf16 model on a HIP device, a multi-token 2-D-masked `inputs_embeds`, no labels, no
+    grad, no attention / hidden-state outputs.  Anything else - and any input the kernel path rejects (a 4-D mask, a rope type it does
+    not implement, ...) - is the reference's own forward."""
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, image_sizes=None, return_dict=None,
                 cache_position=None, **kwargs):
         if inputs_embeds is None and images is not None:
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = self.prepare_inputs_labels_for_multimodal(
                 input_ids, position_ids, attention_mask, past_key_values, labels, images, image_sizes)
-        eligible = (inputs_embeds is not None and inputs_embeds.dim() == 3 and inputs_embeds.shape[1] > 1 and labels is None
-                    and not torch.is_grad_enabled() and inputs_embeds.device.type == "cuda" and _cache_is_empty(past_key_values)
-                    and not output_attentions and not output_hidden_states and return_dict is not False)
-        if not eligible:
+
+        def reference():
             return orig_forward(self, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, past_key_values=past_key_values,
                                 inputs_embeds=inputs_embeds, labels=labels, use_cache=use_cache, output_attentions=output_attentions,
                                 output_hidden_states=output_hidden_states, return_dict=return_dict, cache_position=cache_position, **kwargs)
-        from transformers import DynamicCache
+
+        use = use_cache if use_cache is not None else getattr(self.config, "use_cache", False)
+        eligible = (inputs_embeds is not None and inputs_embeds.dim() == 3 and inputs_embeds.shape[1] > 1 and labels is None
+                    and not torch.is_grad_enabled() and inputs_embeds.device.type == "cuda"
+                    and (any_dtype or (inputs_embeds.dtype == torch.bfloat16 and self.lm_head.weight.dtype == torch.bfloat16)) and bool(use) and _is_fresh_dynamic_cache(past_key_values)
+                    and (attention_mask is None or attention_mask.dim() == 2)
+                    and not output_attentions and not output_hidden_states and return_dict is not False)
+        if not eligible:
+            return reference()
         from transformers.modeling_outputs import CausalLMOutputWithPast
         from .qwen2_prefill import Qwen2Prefill
-        key = tuple((p.data_ptr(), p._version) for p in (self.lm_head.weight, self.model.layers[0].self_attn.q_proj.weight,
-                                                          self.model.layers[-1].mlp.down_proj.weight, self.model.norm.weight))
-        pre = getattr(self, "_fvhd_prefill_ctx", None)
-        if pre is None or pre[0] != key:
-            pre = (key, Qwen2Prefill.from_hf(self))
-            object.__setattr__(self, "_fvhd_prefill_ctx", pre)
-        if position_ids is None and attention_mask is not None:          # as prepare_inputs_for_generation derives them from the mask
-            position_ids = torch.clamp(attention_mask.long().cumsum(-1) - 1, min=0)
-        want_cache = use_cache is not False
-        out = pre[1](inputs_embeds, attention_mask, position_ids, return_kv=want_cache)
-        cache = None
-        if want_cache:
-            logits, k, v = out
-            cache = past_key_values if past_key_values is not None else DynamicCache()
-            for layer in range(k.shape[0]):
-                cache.update(k[layer].to(inputs_embeds.dtype), v[layer].to(inputs_embeds.dtype), layer)
-        else:
-            logits = out
-        return CausalLMOutputWithPast(loss=None, logits=logits[:, None, :], past_key_values=cache)
+        try:
+            pre = prefill_context(self)
+            pos = position_ids
+            if pos is None and attention_mask is not None:               # as prepare_inputs_for_generation derives them from the mask
+                pos = torch.clamp(attention_mask.long().cumsum(-1) - 1, min=0)
+            logits, k, v = pre(inputs_embeds, attention_mask, pos, return_kv=True)
+        except (NotImplementedError, ValueError, KeyError) as e:         # an input / architecture the kernels do not cover
+            if not getattr(self, "_fvhd_prefill_warned", False):
+                import warnings
+                warnings.warn(f"ml_fastvlm_amd: prefill stays on the reference forward ({type(e).__name__}: {e})")
+                object.__setattr__(self, "_fvhd_prefill_warned", True)
+            return reference()
+        for layer in range(k.shape[0]):
+            past_key_values.update(k[layer].to(inputs_embeds.dtype), v[layer].to(inputs_embeds.dtype), layer)
+        return CausalLMOutputWithPast(loss=None, logits=logits[:, None, :], past_key_values=past_key_values)
     forward._fvhd_prefill = True
     forward._fvhd_orig = orig_forward
     return forward
+
+
+def prefill_context(model):
+    """The `Qwen2Prefill` context of a (Llava)Qwen2ForCausalLM, built on first use and rebuilt when its weights change (in place or by
+    re-assignment).  `install_into_llava(prefill=True)` users call this once after loading the model so that the packing (device-to-device
+    copies, ~0.1 s for 0.5B) is not part of the first request's TTFT."""
+    from .qwen2_prefill import Qwen2Prefill
+    key = tuple((p.data_ptr(), p._version) for p in (model.lm_head.weight, model.model.layers[0].self_attn.q_proj.weight,
+                                                      model.model.layers[-1].mlp.down_proj.weight, model.model.norm.weight))
+    pre = getattr(model, "_fvhd_prefill_ctx", None)
+    if pre is None or pre[0] != key:
+        pre = (key, Qwen2Prefill.from_hf(model))
+        object.__setattr__(model, "_fvhd_prefill_ctx", pre)
+    return pre[1]
 
 
 def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, image_sizes=None):

@@ -56,7 +56,8 @@ extern "C" int fvhd_launch_rmsnorm(hipStream_t st, const void* x, void* y, const
 // One thread = 4 consecutive i of one head of one row.  With kcache / vcache != null the rotated k and the v heads are also written
 // to the KV cache [B][nkv][T][HD] (the layout of transformers' DynamicCache layers) for a decode loop to continue from.
 __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const long* __restrict__ pos, const float* __restrict__ table,
-                                                   bf16* __restrict__ kcache, bf16* __restrict__ vcache, int M, int T, int nh, int nkv, int HD, int P)
+                                                   bf16* __restrict__ kcache, bf16* __restrict__ vcache, int M, int T, int nh, int nkv, int HD, int P,
+                                                   float neg_log2_theta_2_over_hd)
 {
     const int per_head = HD / 8;                                 // threads per head: 4 i's each, HD / 2 i's
     const int nheads = nh + nkv + (vcache ? nkv : 0);
@@ -76,10 +77,27 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const
         return;
     }
     bf16* xr = qkv + (size_t)row * width + head * HD;
-    long p = pos ? pos[row] : (long)(row % T);
-    p = p < 0 ? 0 : (p >= P ? P - 1 : p);
-    const float* tb = table + ((size_t)p * (HD / 2) + i4) * 2;
-    const f32x4 cs0 = *(const f32x4*)tb, cs1 = *(const f32x4*)(tb + 4);     // (cos, sin) of i4, i4+1 | i4+2, i4+3
+    const long p = pos ? pos[row] : (long)(row % T);
+    f32x4 cs0, cs1;                                              // (cos, sin) of i4, i4+1 | i4+2, i4+3
+    if (p >= 0 && p < P) {
+        const float* tb = table + ((size_t)p * (HD / 2) + i4) * 2;
+        cs0 = *(const f32x4*)tb;
+        cs1 = *(const f32x4*)(tb + 4);
+    } else {
+        // a position outside the table (a caller continuing a context longer than the table, or a negative id): the phases are
+        // computed here with the table's own formula - inv_freq_i = theta^(-2i / HD), angle = p * inv_freq_i in fp32 - instead of being
+        // clamped to the table's edge (which gave plausible but wrong logits without an error: advisor, round 3)
+        float cs[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float inv = exp2f((float)(i4 + k) * neg_log2_theta_2_over_hd);
+            const float ang = (float)p * inv;
+            cs[2 * k] = cosf(ang);
+            cs[2 * k + 1] = sinf(ang);
+        }
+        cs0 = f32x4{cs[0], cs[1], cs[2], cs[3]};
+        cs1 = f32x4{cs[4], cs[5], cs[6], cs[7]};
+    }
     const f32x4 a = bf4_to_f32(*(const bf16x4*)(xr + i4)), b = bf4_to_f32(*(const bf16x4*)(xr + i4 + HD / 2));
     const float c[4] = {cs0[0], cs0[2], cs1[0], cs1[2]}, s[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
     f32x4 oa, ob;
@@ -100,12 +118,12 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const
 
 // qkv [M = B*T rows (only these are touched), (nh + 2 nkv) * HD] bf16 in place; pos int64 [M] or null (= t); table fp32 [P][HD/2][2]
 extern "C" int fvhd_launch_rope(hipStream_t st, void* qkv, const long* pos, const float* table, void* kcache, void* vcache,
-                                int M, int T, int nh, int nkv, int HD, int P)
+                                int M, int T, int nh, int nkv, int HD, int P, float theta)
 {
-    if (M <= 0 || T <= 0 || nh <= 0 || nkv <= 0 || HD % 8 || P <= 0 || (kcache == nullptr) != (vcache == nullptr)) return (int)hipErrorInvalidValue;
+    if (M <= 0 || T <= 0 || nh <= 0 || nkv <= 0 || HD % 8 || P <= 0 || !(theta > 0.f) || (kcache == nullptr) != (vcache == nullptr)) return (int)hipErrorInvalidValue;
     const long total = (long)M * (nh + nkv + (vcache ? nkv : 0)) * (HD / 8);
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (bf16*)qkv, pos, table, (bf16*)kcache, (bf16*)vcache,
-                       M, T, nh, nkv, HD, P);
+                       M, T, nh, nkv, HD, P, -log2f(theta) * 2.0f / (float)HD);
     return (int)hipGetLastError();
 }
 

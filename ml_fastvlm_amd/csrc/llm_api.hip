@@ -16,7 +16,7 @@ extern "C" {
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_gemm_splitk(hipStream_t, const void*, const void*, const void*, void*, float*, int, int, int, int);
 int fvhd_launch_rmsnorm(hipStream_t, const void*, void*, const float*, int, int, float);
-int fvhd_launch_rope(hipStream_t, void*, const long*, const float*, void*, void*, int, int, int, int, int, int);
+int fvhd_launch_rope(hipStream_t, void*, const long*, const float*, void*, void*, int, int, int, int, int, int, float);
 int fvhd_launch_llm_attention(hipStream_t, const void*, void*, const unsigned char*, int, int, int, int, int);
 int fvhd_launch_cast_rows(hipStream_t, const void*, int, void*, long);
 int fvhd_launch_gather_rows(hipStream_t, const void*, void*, int, int, int, int);
@@ -90,6 +90,13 @@ struct fvhd_llm {
     char *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *last = nullptr, *lastn = nullptr;
     float *rope = nullptr, *part = nullptr;
     int down_splits = 1;
+    int max_pos = 0;                       // fvhd_llm_set_max_positions (config.max_position_embeddings): rows of the rotary table
+    // A prefill that ran while its stream was being captured put this workspace's pointers into the CALLER's graph.  Such a workspace is
+    // never freed when a later call needs a bigger one: it is retired (kept until fvhd_llm_destroy), so the captured graph keeps
+    // replaying on valid memory.  `generation` counts workspace replacements (fvhd_llm_workspace_generation).
+    bool ws_captured = false;
+    std::vector<char*> retired;
+    int generation = 0;
 };
 
 namespace {
@@ -143,9 +150,11 @@ int ensure_ws(fvhd_llm* c, int B, int T, hipStream_t st, bool check_capture)
         if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
             return lfail("fvhd_llm_prefill: the workspace must grow for this (batch, length) but the stream is being captured - call fvhd_llm_reserve first");
     }
-    // the rotary table covers at least 8192 positions (2 MB at head_dim 64): position ids of a prefill are < seq_len, but a caller that
-    // continues a longer context may pass larger ones; the kernel clamps beyond the table
-    const int tpos = T > 8192 ? T : 8192;
+    // the rotary table covers max_position_embeddings (fvhd_llm_set_max_positions; at most 65536 rows = 16 MB at head_dim 64) or 8192
+    // positions: position ids of a prefill are < seq_len, and a caller continuing a longer context may pass larger ones - beyond the
+    // table the kernel computes the phases itself (llm.hip: rope_kernel), it never clamps
+    const int want_pos = c->max_pos > 0 ? (c->max_pos < 65536 ? c->max_pos : 65536) : 8192;
+    const int tpos = T > want_pos ? T : want_pos;
     const int nrows = rows > c->ws_rows ? rows : c->ws_rows, nb = B > c->ws_batch ? B : c->ws_batch, np = tpos > c->ws_pos ? tpos : c->ws_pos;
     const int lb = (nb + 15) / 16 * 16;
     size_t off = 0;
@@ -156,8 +165,13 @@ int ensure_ws(fvhd_llm* c, int B, int T, hipStream_t st, bool check_capture)
                  o_part = take((size_t)kMaxSplits * nrows * c->H * 4);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return lhip("hipDeviceSynchronize", e);
-    if (c->ws) (void)hipFree(c->ws);
+    if (c->ws) {
+        if (c->ws_captured) c->retired.push_back(c->ws);      // a caller's graph may still replay on it
+        else (void)hipFree(c->ws);
+    }
     c->ws = nullptr;
+    c->ws_captured = false;
+    ++c->generation;
     e = hipMalloc((void**)&c->ws, off);
     if (e != hipSuccess) return lhip("hipMalloc(llm workspace)", e);
     e = hipMemset(c->ws, 0, off);           // the padding rows start (and stay) finite
@@ -239,6 +253,7 @@ void fvhd_llm_destroy(fvhd_llm* c)
     (void)hipDeviceSynchronize();
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->ws) (void)hipFree(c->ws);
+    for (char* p : c->retired) (void)hipFree(p);
     delete c;
 }
 
@@ -283,6 +298,61 @@ int fvhd_llm_set_tensor(fvhd_llm* c, const char* key, const void* host_data, int
     return 0;
 }
 
+// The same tensors from DEVICE memory (a model that already lives on the GPU): matrices bf16, vectors fp32, row-major contiguous, on
+// the context's device.  One device-to-device (2-D) copy per tensor on `stream` - no host round trip (advisor, round 3: from_hf moved
+// 15 GB of a 7B model through the CPU).  The caller keeps `dev_data` alive until the stream has run the copy.
+int fvhd_llm_set_tensor_device(fvhd_llm* c, const char* key, const void* dev_data, int dtype, const int64_t* shape, int ndim, fvhd_stream_t stream)
+{
+    if (!c || !key || !dev_data || !shape) return lfail("fvhd_llm_set_tensor_device: NULL argument");
+    int layer = -1, which = -1;
+    const int idx = tensor_index(c, key, &layer, &which);
+    if (idx < 0) return lfail(std::string("fvhd_llm_set_tensor_device: not a tensor of the Qwen2 decoder stack: ") + key);
+    const size_t H = c->H, hd = c->hd, nh = c->nh, nkv = c->nkv, I = c->I;
+    // destination (offset, rows, cols, row pitch in elements) of every slot; vectors: cols = 0
+    size_t off = 0, rows = 0, cols = 0, pitch = 0;
+    if (layer < 0) {
+        if (which == 0) { off = c->norm_off; rows = H; }
+        else { off = c->lm_off; rows = c->V; cols = H; pitch = H; }
+    } else {
+        const LayerOff& o = c->lo[layer];
+        switch (which) {
+        case 0: off = o.ln1; rows = H; break;
+        case 1: off = o.wqkv; rows = nh * hd; cols = H; pitch = H; break;
+        case 2: off = o.bqkv; rows = nh * hd; break;
+        case 3: off = o.wqkv + nh * hd * H * 2; rows = nkv * hd; cols = H; pitch = H; break;
+        case 4: off = o.bqkv + nh * hd * 4; rows = nkv * hd; break;
+        case 5: off = o.wqkv + (nh + nkv) * hd * H * 2; rows = nkv * hd; cols = H; pitch = H; break;
+        case 6: off = o.bqkv + (nh + nkv) * hd * 4; rows = nkv * hd; break;
+        case 7: off = o.wo; rows = H; cols = nh * hd; pitch = nh * hd; break;
+        case 8: off = o.ln2; rows = H; break;
+        case 9: off = o.wgu; rows = I; cols = H; pitch = 2 * H; break;              // gate rows at even, up rows at odd positions
+        case 10: off = o.wgu + H * 2; rows = I; cols = H; pitch = 2 * H; break;
+        case 11: off = o.wd; rows = H; cols = I; pitch = I; break;
+        }
+    }
+    const bool vec = cols == 0;
+    if (vec ? !(ndim == 1 && (size_t)shape[0] == rows) : !(ndim == 2 && (size_t)shape[0] == rows && (size_t)shape[1] == cols))
+        return lfail(std::string("fvhd_llm_set_tensor_device: bad shape for ") + key);
+    if (dtype != (vec ? FVHD_F32 : FVHD_BF16))
+        return lfail(std::string("fvhd_llm_set_tensor_device: matrices must be bf16 and vectors fp32 on the device (") + key + ")");
+    DevGuard g(c->device);
+    if (g.err != hipSuccess) return lhip("hipSetDevice", g.err);
+    hipError_t e = vec ? hipMemcpyAsync(c->wdev + off, dev_data, rows * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream)
+                       : hipMemcpy2DAsync(c->wdev + off, pitch * 2, dev_data, cols * 2, cols * 2, rows, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return lhip("hipMemcpyAsync(llm weights, device to device)", e);
+    c->got[idx] = 1;
+    return 0;
+}
+
+int fvhd_llm_set_max_positions(fvhd_llm* c, int max_position_embeddings)
+{
+    if (!c || max_position_embeddings <= 0) return lfail("fvhd_llm_set_max_positions: bad argument");
+    c->max_pos = max_position_embeddings;      // takes effect at the next workspace (re)allocation: call it before fvhd_llm_reserve
+    return 0;
+}
+
+int fvhd_llm_workspace_generation(const fvhd_llm* c) { return c ? c->generation : -1; }
+
 int fvhd_llm_finalize(fvhd_llm* c)
 {
     if (!c) return lfail("fvhd_llm_finalize: ctx is NULL");
@@ -317,6 +387,10 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
     hipStream_t st = (hipStream_t)stream;
     int e = ensure_ws(c, batch, seq_len, st, true);
     if (e) return e;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) c->ws_captured = true;
+    }
     const int B = batch, T = seq_len, M = B * T, Mp = (M + 255) / 256 * 256;
     const int H = c->H, I = c->I, nh = c->nh, nkv = c->nkv, hd = c->hd;
     const char* w = c->wdev;
@@ -328,7 +402,7 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
         LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln1), Mp, H, c->eps), "rmsnorm 1");
         LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wqkv, (const float*)(w + o.bqkv), nullptr, nullptr, c->qkv, Mp, c->qkvw, H, EPI_BIAS, FVHD_BF16), "qkv gemm");
         LCHECK(fvhd_launch_rope(st, c->qkv, (const long*)position_ids, c->rope, k_cache ? (char*)k_cache + l * cache_layer : nullptr,
-                                v_cache ? (char*)v_cache + l * cache_layer : nullptr, M, T, nh, nkv, hd, c->ws_pos), "rope");
+                                v_cache ? (char*)v_cache + l * cache_layer : nullptr, M, T, nh, nkv, hd, c->ws_pos, c->theta), "rope");
         LCHECK(fvhd_launch_llm_attention(st, c->qkv, c->att, key_valid, B, T, nh, nkv, hd), "attention");
         LCHECK(fvhd_launch_gemm(st, c->att, w + o.wo, nullptr, nullptr, c->h, c->h, Mp, H, nh * hd, EPI_RESID, FVHD_BF16), "o_proj gemm");
         LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln2), Mp, H, c->eps), "rmsnorm 2");
@@ -369,10 +443,10 @@ int fvhd_op_rmsnorm(fvhd_stream_t st, const void* x, void* y, const float* w, in
 }
 
 int fvhd_op_rope(fvhd_stream_t st, void* qkv, const int64_t* pos, const float* table, void* k_cache, void* v_cache, int M, int T, int n_heads,
-                 int n_kv_heads, int head_dim, int table_positions)
+                 int n_kv_heads, int head_dim, int table_positions, float rope_theta)
 {
     if (!qkv || !table) return lfail("fvhd_op_rope: NULL pointer");
-    int e = fvhd_launch_rope((hipStream_t)st, qkv, (const long*)pos, table, k_cache, v_cache, M, T, n_heads, n_kv_heads, head_dim, table_positions);
+    int e = fvhd_launch_rope((hipStream_t)st, qkv, (const long*)pos, table, k_cache, v_cache, M, T, n_heads, n_kv_heads, head_dim, table_positions, rope_theta);
     return e ? lhip("fvhd_op_rope", (hipError_t)e) : 0;
 }
 

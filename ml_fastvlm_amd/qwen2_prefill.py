@@ -57,6 +57,9 @@ class Qwen2Prefill:
         self = cls(dev.index if dev.index is not None else torch.cuda.current_device(), cfg.hidden_size, cfg.num_hidden_layers,
                    cfg.num_attention_heads, cfg.num_key_value_heads, head_dim, cfg.intermediate_size, cfg.vocab_size,
                    getattr(cfg, "rms_norm_eps", 1e-6), float(theta if theta is not None else 1e6))
+        mpe = getattr(cfg, "max_position_embeddings", None)
+        if mpe:                                   # rows of the rotary table; positions beyond it are computed in the kernel, never clamped
+            _lib.check(_lib.load().fvhd_llm_set_max_positions(self._h, int(mpe)), "fvhd_llm_set_max_positions")
         self.load_state_dict(model.state_dict())
         return self
 
@@ -85,11 +88,25 @@ class Qwen2Prefill:
                        "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")
 
     def _set(self, lib, key: str, t: torch.Tensor) -> None:
+        """A tensor that already lives on this context's device is packed by ONE device-to-device copy (`fvhd_llm_set_tensor_device`:
+        matrices as bf16, vectors as fp32 - converted on the device when the module holds another dtype); only host tensors take the
+        host path.  (Round 3 moved every tensor device -> CPU -> temporary -> device: 15 GB through the host for the 7B model.)  Note the
+        footprint: the packed copy (q|k|v concatenated, gate / up interleaved, bf16) lives NEXT to the module's own weights, which the
+        stock decode loop keeps using - 2x the LLM's weight bytes on the device (0.99 GB / 15.2 GB more for Qwen2-0.5B / 7B)."""
         t = t.detach()
+        shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+        if t.device.type == "cuda" and t.device == self.device:
+            want = torch.bfloat16 if t.dim() == 2 else torch.float32
+            d = t.to(want).contiguous()
+            with torch.cuda.device(self.device):
+                _lib.check(lib.fvhd_llm_set_tensor_device(self._h, key.encode(), C.c_void_p(d.data_ptr()), _lib.dtype_code(want), shape, t.dim(),
+                                                          _lib.stream_ptr(self.device)), f"fvhd_llm_set_tensor_device({key})")
+            if d is not t and d.data_ptr() != t.data_ptr():
+                d.record_stream(torch.cuda.current_stream(self.device))      # the temporary outlives the enqueued copy
+            return
         if t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             t = t.float()
         t = t.to("cpu").contiguous()
-        shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
         _lib.check(lib.fvhd_llm_set_tensor(self._h, key.encode(), C.c_void_p(t.data_ptr()), _lib.dtype_code(t.dtype), shape, t.dim()),
                    f"fvhd_llm_set_tensor({key})")
 
@@ -136,6 +153,9 @@ class Qwen2Prefill:
         """-> logits [B, vocab] fp32 of the last position; with return_kv also (k, v): bf16 [n_layers, B, n_kv_heads, T, head_dim]."""
         x, am, pos = self._check(inputs_embeds, attention_mask, position_ids)
         B, T = x.shape[:2]
+        if out is not None and (not isinstance(out, torch.Tensor) or tuple(out.shape) != (B, self.vocab) or out.dtype != torch.float32
+                                or out.device != self.device or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous fp32 tensor [{B}, {self.vocab}] on {self.device} (its raw pointer goes to the kernel)")
         logits = out if out is not None else torch.empty((B, self.vocab), device=self.device, dtype=torch.float32)
         kc = vc = None
         if return_kv:
@@ -145,6 +165,12 @@ class Qwen2Prefill:
             _lib.check(_lib.load().fvhd_llm_prefill(self._h, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr(am), _lib.ptr(pos), B, T,
                                                     _lib.ptr(logits), _lib.ptr(kc), _lib.ptr(vc), _lib.stream_ptr(self.device)), "fvhd_llm_prefill")
         return (logits, kc, vc) if return_kv else logits
+
+    @property
+    def workspace_generation(self) -> int:
+        """increments whenever the library replaced its workspace (a graph the caller captured before stays valid - the old workspace is
+        kept alive - but only a re-capture uses the new one)"""
+        return int(_lib.load().fvhd_llm_workspace_generation(self._h))
 
     def hidden_states(self, rows: int) -> torch.Tensor:
         """tests: the residual stream after the last decoder layer of the previous prefill, [rows, hidden] bf16"""

@@ -35,6 +35,24 @@ def test_bench_distributed_path_world1_nccl():
     d = _torchrun_bench(1)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["global_batch"] == 4
     assert d["config"]["collective"] == "all_gather_into_tensor over nccl (RCCL), world 1"
+    assert d["config"]["gather_side"] == "after"
+    # FastVLM-7B width: the gather sits BEFORE the projector (3072-wide tower tokens cross the wire, every rank projects the gathered
+    # batch through fvhd_project) - the RCCL leg of that side, at world 1
+    d7 = _torchrun_bench(1, ("--hidden", "3584"))
+    assert d7["config"]["gather_side"] == "before" and d7["value"] > 0
+
+
+def test_ttft_distributed_harness_world1_nccl():
+    """BASELINE.json configs[3] as a runnable harness (`bench.py --ttft --gpus N`): encode sharded over the ranks -> RCCL all-gather of the
+    visual tokens at the projector boundary (before it at the 7B width) -> Qwen2 prefill of the rank's own sequences -> first token.
+    World 1 on the single-GPU box: process group, collective, barrier and max-reduce all execute; 2 decoder layers of each width."""
+    for hidden, side in ((3584, "before"), (896, "after")):
+        d = _torchrun_bench(1, ("--ttft", "--hidden", str(hidden), "--llm-layers", "2", "--batch", "2"))
+        c = d["config"]
+        assert d["unit"] == "ms" and d["value"] > 0 and d["higher_is_better"] is False and d["n_gpus"] == 1
+        assert c["gather_side"] == side and c["world"] == 1 and c["global_batch"] == 2 and c["kv_cache_written"] is True
+        assert c["prompt_tokens"] == 24 + 16 and c["prefill_roofline"]["achieved"] > 0
+        assert f"configs[3]" in c["workload"]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")

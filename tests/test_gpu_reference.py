@@ -131,10 +131,50 @@ def test_reference_generate_with_our_tower_underneath():
 
         # ... and with the PREFILL of the language model on the hand-written Qwen2 kernels too: first-token logits from
         # fvhd_llm_prefill, second-token logits from the stock decode step running on OUR KV cache
+        # (this model is fp32: the bf16 prefill kernels are an explicit opt-in for it - by default only a bf16 model takes them)
         fv.install_into_llava(splice=True, prefill=True)
         assert getattr(lq.LlavaQwen2ForCausalLM.forward, "_fvhd_prefill", False)
+        run(ours_model)
+        assert getattr(ours_model, "_fvhd_prefill_ctx", None) is None, "an fp32 model must keep the reference's forward unless opted in"
+        fv.install_into_llava(splice=True, prefill=True, prefill_any_dtype=True)
         seq_p, logits_p, logits2_p = run(ours_model)
         assert getattr(ours_model, "_fvhd_prefill_ctx", None) is not None, "generate() did not reach the Qwen2 prefill kernels"
+
+        # ---- the DEFAULT patch on a bf16 model (what predict.py-style inference loads): generate() takes the kernels, every other
+        # caller keeps the reference's forward (advisor, round 3) ----
+        fv.install_into_llava(splice=True, prefill=True)
+        bf = ours_model.to(torch.bfloat16)
+        object.__setattr__(bf, "_fvhd_prefill_ctx", None)
+        with torch.inference_mode():
+            emb = torch.randn(2, 9, hidden, device=DEV, dtype=torch.bfloat16)
+            scored = bf(inputs_embeds=emb)                                           # a scoring forward: no cache object, all positions wanted
+            assert scored.logits.shape == (2, 9, 1024), "a plain forward must keep its [B, T, vocab] logits"
+            assert getattr(bf, "_fvhd_prefill_ctx", None) is None, "a plain forward must not take the last-position-only kernel path"
+
+        def gen(model, ids_, mask_, n=4):
+            with torch.inference_mode(), torch.backends.cudnn.flags(enabled=False):
+                out = model.generate(ids_.to(DEV), images=images.to(DEV, torch.bfloat16), image_sizes=[(256, 256)] * 3, attention_mask=mask_.to(DEV),
+                                     do_sample=False, max_new_tokens=n, use_cache=True, output_scores=True, return_dict_in_generate=True, pad_token_id=0)
+            return out.sequences.cpu(), [s.float().cpu() for s in out.scores]
+        lmask = torch.ones_like(ids)
+        lmask[1, :3] = 0                                                             # a LEFT-padded sample (padding_side of generation)
+        for which, m_ in (("right-padded", mask), ("left-padded", lmask)):
+            bf.config.tokenizer_padding_side = "left" if which == "left-padded" else "right"
+            seq_k, sc_k = gen(bf, ids, m_)
+            assert getattr(bf, "_fvhd_prefill_ctx", None) is not None, "generate() on a bf16 model must reach the Qwen2 prefill kernels"
+            lq.LlavaQwen2ForCausalLM.forward = lq.LlavaQwen2ForCausalLM.forward._fvhd_orig
+            seq_s, sc_s = gen(bf, ids, m_)                                           # same bf16 model, stock prefill
+            fv.install_into_llava(splice=True, prefill=True)
+            rel, cos, _ = _metrics(sc_k[0], sc_s[0])
+            print(f"bf16 model, {which}: first-token logits kernels vs stock bf16 prefill rel-L2 {rel:.3e} cos {cos:.6f}; tokens {seq_k.tolist()} vs {seq_s.tolist()}")
+            assert rel <= 4e-2 and cos >= 0.999, (which, rel, cos)
+            for b in range(3):                                                       # greedy tokens agree while every margin exceeds the error
+                for t in range(len(sc_s)):
+                    top2 = sc_s[t][b].topk(2).values
+                    if (top2[0] - top2[1]) <= 2 * (sc_k[t][b] - sc_s[t][b]).abs().max():
+                        break
+                    assert seq_k[b, t] == seq_s[b, t], (which, b, t)
+        bf.config.tokenizer_padding_side = "right"
     finally:
         (enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images,
          arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal, lq.LlavaQwen2ForCausalLM.forward) = saved

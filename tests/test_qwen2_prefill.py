@@ -164,7 +164,7 @@ def test_rope_in_place_and_kv_cache(hd, nh, nkv):
     qd = qkv.to(DEV, torch.bfloat16)
     kc = torch.zeros(B, nkv, T, hd, device=DEV, dtype=torch.bfloat16)
     vc = torch.zeros_like(kc)
-    _lib.check(lib.fvhd_op_rope(_stream(), _p(qd), _p(pos.to(DEV)), _p(table), _p(kc), _p(vc), B * T, T, nh, nkv, hd, T), "rope")
+    _lib.check(lib.fvhd_op_rope(_stream(), _p(qd), _p(pos.to(DEV)), _p(table), _p(kc), _p(vc), B * T, T, nh, nkv, hd, T, 1e6), "rope")
     torch.cuda.synchronize()
     x = qkv.view(B, T, nh + 2 * nkv, hd)
     q, k, v = x[:, :, :nh].transpose(1, 2), x[:, :, nh:nh + nkv].transpose(1, 2), x[:, :, nh + nkv:].transpose(1, 2)
@@ -178,9 +178,16 @@ def test_rope_in_place_and_kv_cache(hd, nh, nkv):
     assert torch.equal(vc.float().cpu(), v), "v cache = the v rows"
     # default positions (NULL) = 0..T-1 per sequence
     qd2 = qkv.to(DEV, torch.bfloat16)
-    _lib.check(lib.fvhd_op_rope(_stream(), _p(qd2), _p(None), _p(table), _p(None), _p(None), B * T, T, nh, nkv, hd, T), "rope")
+    _lib.check(lib.fvhd_op_rope(_stream(), _p(qd2), _p(None), _p(table), _p(None), _p(None), B * T, T, nh, nkv, hd, T, 1e6), "rope")
     cos, sin = QO.rope_cos_sin(torch.arange(T)[None].expand(B, T), hd, 1e6)
     _close(qd2.float().cpu().view(B, T, -1, hd)[:, :, :nh].transpose(1, 2), QO.apply_rope(q, k, cos, sin)[0], "rope q default positions")
+    # positions BEYOND the table (a caller continuing a long context): computed in the kernel from theta, not clamped to the table's edge
+    # (advisor, round 3: the clamp gave plausible but wrong phases without an error)
+    far = pos + 40000
+    qd3 = qkv.to(DEV, torch.bfloat16)
+    _lib.check(lib.fvhd_op_rope(_stream(), _p(qd3), _p(far.to(DEV)), _p(table), _p(None), _p(None), B * T, T, nh, nkv, hd, T, 1e6), "rope")
+    cos, sin = QO.rope_cos_sin(far, hd, 1e6)
+    _close(qd3.float().cpu().view(B, T, -1, hd)[:, :, :nh].transpose(1, 2), QO.apply_rope(q, k, cos, sin)[0], "rope q, positions beyond the table")
 
 
 @pytest.mark.gpu
@@ -313,7 +320,6 @@ def test_prefill_hands_its_kv_cache_to_the_transformers_decode_loop():
     with torch.no_grad():
         ref = m(inputs_embeds=x.to(DEV), attention_mask=mask.to(DEV), position_ids=pos.to(DEV), use_cache=True)
         tok = ref.logits[:, -1].argmax(-1)
-        assert torch.equal(tok, logits.argmax(-1)) or True      # (margin-checked in _compare_prefill)
         step_ref = m(input_ids=tok[:, None], past_key_values=ref.past_key_values, use_cache=True,
                      attention_mask=torch.ones(2, 41, device=DEV, dtype=torch.long), position_ids=torch.full((2, 1), 40, device=DEV)).logits[:, -1]
         cache = kv_to_dynamic_cache(kc.float(), vc.float())

@@ -27,9 +27,12 @@ QWEN2 = {   # published architectures (Qwen2 model cards); hidden size selects t
 PROMPT_BEFORE, PROMPT_AFTER = 14, 10      # "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n" | "\nDescribe the image.<|im_end|>\n<|im_start|>assistant\n"
 
 
-def build_llm(hidden: int, dev):
+def build_llm(hidden: int, dev, layers: int = 0):
     from transformers import Qwen2Config, Qwen2ForCausalLM
-    cfg = Qwen2Config(max_position_embeddings=32768, rope_theta=1e6, rms_norm_eps=1e-6, **QWEN2[hidden])
+    arch = dict(QWEN2[hidden])
+    if layers:
+        arch["num_hidden_layers"] = layers
+    cfg = Qwen2Config(max_position_embeddings=32768, rope_theta=1e6, rms_norm_eps=1e-6, **arch)
     cfg._attn_implementation = "sdpa"
     torch.manual_seed(7)
     with torch.device(dev):
@@ -53,11 +56,30 @@ def _capture(fn, dev):
 
 
 @torch.no_grad()
+def prefill_flops(cfg, batch: int, seq: int) -> float:
+    """Algorithmic FLOPs (2 * MAC) of one prefill: the four projections and the SwiGLU MLP of every layer on batch * seq rows, causal
+    attention (each query sees its own position and everything before it), and the lm_head on the LAST position of every sequence only
+    (what `generate` samples the first token from)."""
+    H, L, nh, nkv, I, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size, cfg.vocab_size
+    hd = getattr(cfg, "head_dim", None) or H // nh
+    M = batch * seq
+    per_layer = 2.0 * M * H * (nh + 2 * nkv) * hd + 2.0 * M * nh * hd * H + 2.0 * M * H * 2 * I + 2.0 * M * I * H \
+        + 4.0 * batch * nh * hd * seq * (seq + 1) / 2
+    return L * per_layer + 2.0 * batch * V * H
+
+
+@torch.no_grad()
 def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, graph: bool = False, llm_graph: bool = True, llm_mode: str = None,
-            pad_left: int = 0, return_tokens: bool = False):
+            pad_left: int = 0, return_tokens: bool = False, dist_ctx=None, llm_layers: int = 0):
     """llm_mode: "kernels" | "kernels-graph" | "hf-graph" | "hf-eager" (None: "kernels", or "hf-graph" / "hf-eager" by the legacy
     `llm_graph` flag when FVHD_TTFT_HF=1).  pad_left > 0 masks that many leading prompt tokens of every odd sample (a left-padded
-    batch: attention mask and position ids must reach the prefill - VERDICT r2 weak #10)."""
+    batch: attention mask and position ids must reach the prefill - VERDICT r2 weak #10).
+
+    dist_ctx = (rank, world): BASELINE.json configs[3] - every rank encodes its own `batch` images, the visual tokens of all ranks
+    are all-gathered at the projector boundary (`distributed.encode_images_tower_sharded`: BEFORE the projector when the LLM is wider
+    than the tower's 3072, i.e. the 7B model - every rank then projects the gathered batch -, after it otherwise), and every rank
+    prefills ITS OWN `batch` sequences (data-parallel prefill: the LLM is replicated).  Every step starts at a barrier; the TTFT of a
+    step is the maximum over ranks.  llm_layers > 0 truncates the decoder stack (tests)."""
     import os
     import ml_fastvlm_amd as fv
     from ml_fastvlm_amd import splice as S
@@ -73,9 +95,15 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
     proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=hidden))
     proj.load_state_dict(synth.synthetic_projector_state_dict(hidden, 1234), strict=True)
     tower, proj = tower.to(dev, torch.bfloat16), proj.to(dev, torch.bfloat16)
-    llm = build_llm(hidden, dev)
+    llm = build_llm(hidden, dev, llm_layers)
     table = llm.get_input_embeddings().weight
-    g = torch.Generator().manual_seed(11)
+    rank, world = dist_ctx if dist_ctx is not None else (0, 1)
+    side = None
+    if dist_ctx is not None:
+        import torch.distributed as dist
+        from ml_fastvlm_amd import distributed as D
+        side = D.gather_side(hidden)
+    g = torch.Generator().manual_seed(11 + rank)
     images = torch.rand((batch, 3, res, res), generator=g).to(dev, torch.bfloat16)
     ids = torch.randint(0, 151000, (batch, PROMPT_BEFORE + 1 + PROMPT_AFTER), generator=g)
     ids[:, PROMPT_BEFORE] = S.IMAGE_TOKEN_INDEX
@@ -99,7 +127,13 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
         note = "hand-written kernels (fvhd_llm_prefill), plain launches"
         if llm_mode == "kernels-graph":
             try:
-                hip_graph, static_tok = _capture(lambda: pre(static_in, static_mask, static_pos, out=logits).argmax(-1), dev)
+                kv_keep = []
+
+                def graphed():
+                    lg, kc_, vc_ = pre(static_in, static_mask, static_pos, return_kv=True, out=logits)
+                    kv_keep[:] = [kc_, vc_]          # the captured launches write into these buffers on every replay
+                    return lg.argmax(-1)
+                hip_graph, static_tok = _capture(graphed, dev)
                 note = "hand-written kernels (fvhd_llm_prefill), one hipGraph replay"
             except Exception as e:                   # noqa: BLE001
                 hip_graph, note = None, f"hand-written kernels, plain launches (graph capture failed: {type(e).__name__})"
@@ -117,9 +151,21 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
     else:
         note = "stock transformers module, eager"
 
+    def gather(t):                           # all_gather_tokens short-cuts world 1; the forced path still issues the collective
+        if world == 1:
+            out_ = torch.empty_like(t)
+            dist.all_gather_into_tensor(out_, t.contiguous())
+            return out_
+        return D.all_gather_tokens(t, batch * world)
+
     def once():
         ev[0].record()
-        feats = fv.encode_images(tower, proj, images)
+        if dist_ctx is None:
+            feats = fv.encode_images(tower, proj, images)
+        elif side == "after":                # 0.5B / 1.5B: project the rank's own images, gather the narrow projected tokens
+            feats = gather(fv.encode_images(tower, proj, images))[rank * batch:(rank + 1) * batch]
+        else:                                # 7B: gather the 3072-wide tower tokens, project the gathered batch (fvhd_project)
+            feats = fv.project(tower, proj, gather(tower(images)))[rank * batch:(rank + 1) * batch]
         ev[1].record()
         _, pos, am, _, embeds, _ = S.multimodal_splice(ids, pos0, mask, None, feats, table, "left" if pad_left else "right")
         ev[2].record()
@@ -130,7 +176,9 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
             hip_graph.replay()
             tok = static_tok
         elif pre is not None:
-            tok = pre(embeds, am, pos, out=logits).argmax(-1)
+            # return_kv=True: the KV cache `generate` continues from is part of the prefill (advisor, round 3: the stock baseline runs with
+            # use_cache=True, so must this)
+            tok = pre(embeds, am, pos, return_kv=True, out=logits)[0].argmax(-1)
         else:
             out = llm(inputs_embeds=embeds, attention_mask=am, position_ids=pos, use_cache=True, logits_to_keep=1)
             tok = out.logits[:, -1].argmax(-1)
@@ -144,20 +192,38 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
     wall, parts = [], []
     for _ in range(steps):
         torch.cuda.synchronize()
+        if dist_ctx is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         tok, _ = once()
         first = tok.cpu()                              # the first token reaches the host: end of TTFT
-        wall.append(1e3 * (time.perf_counter() - t0))
+        dt = 1e3 * (time.perf_counter() - t0)
+        if dist_ctx is not None:                       # a step's TTFT = the slowest rank's
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        wall.append(dt)
         parts.append([ev[i].elapsed_time(ev[i + 1]) for i in range(3)])
     assert first.shape == (batch,)
     wall.sort()
     med = lambda xs: sorted(xs)[len(xs) // 2]
     n_par = sum(p.numel() for p in llm.parameters())
+    pf_ms = med([p[2] for p in parts])
+    pf_tf = prefill_flops(llm.config, batch, seq) / (pf_ms * 1e-3) / 1e12
     r = {"ttft_ms_median": round(wall[len(wall) // 2], 3), "ttft_ms_min": round(wall[0], 3), "ttft_ms_max": round(wall[-1], 3),
          "encode_images_ms": round(med([p[0] for p in parts]), 3), "splice_ms": round(med([p[1] for p in parts]), 3),
          "prefill_first_token_ms": round(med([p[2] for p in parts]), 3), "prefill_mode": note, "llm_mode": llm_mode,
          "batch": batch, "prompt_tokens": int(seq), "image_tokens": (res // 64) ** 2,
-         "llm": f"Qwen2 architecture, hidden {hidden}, {n_par / 1e9:.2f} B parameters, random bf16 weights", "steps": steps}
+         "llm": f"Qwen2 architecture, hidden {hidden}, {llm.config.num_hidden_layers} layers, {n_par / 1e9:.2f} B parameters, random bf16 weights", "steps": steps,
+         "kv_cache_written": bool(pre is not None or llm_mode.startswith("hf")),
+         # the prefill against the dense bf16 MFMA peak (2.5 PF/s): algorithmic FLOPs of prefill_flops() / the event-timed prefill leg
+         # (incl. the argmax and - on the kernel path - the KV-cache writes)
+         "prefill_roofline": {"bound": "mfma", "achieved": round(pf_tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(pf_tf / 2500.0, 4),
+                              "flops": prefill_flops(llm.config, batch, seq), "rows": batch * seq}}
+    if dist_ctx is not None:
+        r.update({"world": world, "gather_side": side, "global_batch": batch * world,
+                  "collective": f"all_gather_into_tensor over {dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}), world {world}"})
     if return_tokens:
         r["first_tokens"] = first.tolist()
     return r
