@@ -150,7 +150,18 @@ def reparameterize_state_dict(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, 
 
 
 def load_training_checkpoint(tower, sd: Dict[str, torch.Tensor], strict: bool = True):
-    """Re-parameterise `sd` if it comes from the training graph and load it into `tower.vision_tower.model`."""
+    """Re-parameterise `sd` if it comes from the training graph and load it into `tower.vision_tower.model`.
+
+    A checkpoint saved from a bare `FastViT` carries the ImageNet classifier `head.{weight,bias}` (`mci.py:1412-1416`); `MCi` replaces
+    that module by `GlobalPool2D` (`mobileclip/__init__.py:81-87`), whose `head.proj` is dead on the encode_images() path: the
+    classifier keys are dropped and a missing `head.proj` keeps the tower's current value, so `strict` still vouches for every tensor
+    the path uses."""
+    sd = dict(sd)
     if is_training_state_dict(sd):
         sd = reparameterize_state_dict(sd)
-    return tower.vision_tower.model.load_state_dict(sd, strict=strict)
+    model = tower.vision_tower.model
+    if "head.proj" not in sd:
+        sd.pop("head.weight", None)
+        sd.pop("head.bias", None)
+        sd["head.proj"] = model.state_dict()["head.proj"]
+    return model.load_state_dict(sd, strict=strict)
