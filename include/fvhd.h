@@ -91,6 +91,26 @@ int fvhd_project(fvhd_ctx* ctx, const void* tokens, int in_dtype, int rows, void
 int fvhd_encode_images(fvhd_ctx* ctx, const void* images, int img_dtype, int batch, void* out, int out_dtype,
                        fvhd_stream_t stream);
 
+/* ---- precision of the fused ConvFFN's hidden activation ------------------------------------------
+ * ConvFFN.fc1 -> GELU -> fc2 (mci.py:922-926) runs for C in {96,192,384} as ONE kernel whose hidden activation never reaches HBM.  By
+ * default it is kept as gelu(x)/4 in IEEE half (FVHD_FFN_HALF: 11 mantissa bits, better than the bf16 the reference's bf16 execution
+ * carries, but |fc1 output| > 262 016 SATURATES where bf16 / fp32 carry on).  The same kernel exists with an f32 GELU and a bf16 hidden
+ * operand (FVHD_FFN_BF16: no range limit, ~3-7 % slower); both are compiled in and both weight images are packed, so the choice is a
+ * per-block run-time switch:
+ *   fvhd_set_ffn_precision / fvhd_get_ffn_precision  - by step index (fvhd_step_info); get returns -1 for a step without a fused ConvFFN.
+ *     A block whose |4 * fc2.weight| would overflow f16 starts as FVHD_FFN_BF16.
+ *   fvhd_audit_ranges - one eager pass over `images` (a calibration batch of the deployment's real inputs) that also materialises every
+ *     ConvFFN's fc1 output and reduces it to max |.|: max_abs_out[fvhd_num_steps] (0 for steps without a ConvFFN; Inf / NaN if the fc1
+ *     output itself overflowed) and, when switch_above > 0, switches every fused block whose maximum exceeds it (or is not finite) to
+ *     FVHD_FFN_BF16, reporting how many in *n_switched.  A margin below the 262 016 limit (the Python wrapper uses 65 504 = a factor 4)
+ *     covers inputs hotter than the calibration batch.  Synchronises `stream`; not during capture.  max_abs_out / n_switched may be NULL. */
+#define FVHD_FFN_HALF 0
+#define FVHD_FFN_BF16 1
+int fvhd_set_ffn_precision(fvhd_ctx* ctx, int step, int precision);
+int fvhd_get_ffn_precision(const fvhd_ctx* ctx, int step);
+int fvhd_audit_ranges(fvhd_ctx* ctx, const void* images, int img_dtype, int batch, float switch_above, float* max_abs_out,
+                      int* n_switched, fvhd_stream_t stream);
+
 /* geometry helpers (mobileclip_encoder.py:106-116) */
 int fvhd_num_tokens(const fvhd_ctx* ctx);   /* (R/64)^2 */
 int fvhd_hidden_size(const fvhd_ctx* ctx);  /* 3072     */
@@ -175,13 +195,14 @@ int fvhd_op_se_head(fvhd_stream_t stream, const void* y, float* pooled, float* s
  * fc2.weight [C][4C] (fp32, the reference's layouts): per chunk of 32 hidden units a 64*C-byte image in the kernel's
  * LDS byte order (XOR-swizzled 16-B slots; fc2's hidden axis permuted inside the chunk so that position 16kb+8half+j
  * holds hidden unit 16kb+8(j>>2)+4half+(j&3)).  Sizes: w1img (4C/32 + 1) * 64*C bytes (last chunk zero), w2img 4C/32 * 64*C.
- * Element types of the images (half-precision GELU, csrc/ffn_fused.hip): bf16(fc1 / 4) and IEEE half f16(4 * fc2) - the kernel's
- * hidden activation is gelu(x) / 4 in f16 (11 mantissa bits instead of bf16's 8; |Phi error| <= 1.4e-3; saturates at
- * |x| = 262016).  The images are opaque to callers: pack with fvhd_ffn_pack of the same library build. */
+ * Element types of the images by `precision`: FVHD_FFN_HALF - bf16(fc1 / 4) and IEEE half f16(4 * fc2), the kernel's hidden activation
+ * is gelu(x) / 4 in f16 (11 mantissa bits instead of bf16's 8; |Phi error| <= 1.4e-3; saturates at |x| = 262016); FVHD_FFN_BF16 -
+ * bf16(fc1), bf16(fc2), f32 GELU, bf16 hidden operand (no range limit).  The images are opaque to callers: pack with fvhd_ffn_pack of
+ * the same library build and run them with the SAME precision. */
 int fvhd_ffn_fused_supported(int C);
-int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img);
+int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img, int precision);
 int fvhd_op_ffn_fused(fvhd_stream_t stream, const void* A, const void* w1img, const float* b1, const void* w2img,
-                      const float* b2, const float* ls, void* X, int M, int C);
+                      const float* b2, const float* ls, void* X, int M, int C, int precision);
 
 /* Image preprocessing of ONE image on the device - `process_images` / `expand2square` (llava/mm_utils.py:154-184) around the
  * tower's CLIPImageProcessor (mobileclip_encoder.py:45-49): canvas of the background colour, Pillow's 8-bit bicubic resample

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FVHD_LIB") or os.path.join(_HERE, "libfvhd.so")
 
 F32, F16, BF16 = 0, 1, 2
+FFN_HALF, FFN_BF16 = 0, 1        # precision of the fused ConvFFN's hidden activation (include/fvhd.h)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RESID, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3, 4, 5
 
 _lib = None
@@ -54,9 +55,12 @@ def _declare(lib) -> None:
         "fvhd_op_stem_conv": (ci, [vp, vp, ci, vp, vp, vp, ci, ci]),
         "fvhd_op_stem_fused": (ci, [vp, vp, ci, vp, vp, vp, vp, vp, ci, ci]),
         "fvhd_op_se_head": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
-        "fvhd_op_ffn_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci]),
+        "fvhd_op_ffn_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]),
         "fvhd_ffn_fused_supported": (ci, [ci]),
-        "fvhd_ffn_pack": (ci, [ci, vp, vp, vp, vp]),
+        "fvhd_ffn_pack": (ci, [ci, vp, vp, vp, vp, ci]),
+        "fvhd_set_ffn_precision": (ci, [vp, ci, ci]),
+        "fvhd_get_ffn_precision": (ci, [vp, ci]),
+        "fvhd_audit_ranges": (ci, [vp, vp, ci, ci, cf, C.POINTER(C.c_float), C.POINTER(ci), vp]),
         "fvhd_op_preprocess": (ci, [vp, vp, ci, ci, C.c_int64, ci, ci, C.c_uint32, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp, ci, vp, ci]),
         "fvhd_op_splice": (ci, [vp] * 12 + [ci, ci, ci, ci, C.c_int64, C.c_int64, ci, ci]),
         "fvhd_llm_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci, ci, cf, cf]),
@@ -197,6 +201,22 @@ class Context:
     def set_batch_invariant(self, on: bool) -> None:
         """kernel choice by image shape only: an image gives the same bits in any batch (default off = fastest kernel per batch size)."""
         check(load().fvhd_set_batch_invariant(self._h, int(bool(on))), "fvhd_set_batch_invariant")
+
+    def ffn_precision(self, step: int) -> int:
+        """FFN_HALF / FFN_BF16 of the fused ConvFFN of `step`, -1 for a step without one"""
+        return load().fvhd_get_ffn_precision(self._h, int(step))
+
+    def set_ffn_precision(self, step: int, precision: int) -> None:
+        check(load().fvhd_set_ffn_precision(self._h, int(step), int(precision)), "fvhd_set_ffn_precision")
+
+    def audit_ranges(self, images, switch_above: float = 65504.0):
+        """One eager pass over `images`: -> (max |fc1 output| per step, number of blocks switched to FFN_BF16)."""
+        n = load().fvhd_num_steps(self._h)
+        out = (C.c_float * n)()
+        sw = C.c_int(0)
+        check(load().fvhd_audit_ranges(self._h, ptr(images), dtype_code(images.dtype), images.shape[0], float(switch_above), out, C.byref(sw),
+                                       stream_ptr(images.device)), "fvhd_audit_ranges")
+        return [out[i] for i in range(n)], sw.value
 
     def set_graph(self, on: bool) -> None:
         """replay the interior steps as one hipGraph per batch size (launch-bound small batches)."""

@@ -302,7 +302,7 @@ template <int C> FVHD_DEV int ffn_slot_of(int id)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One tile (32 * WAVES rows) per workgroup: the small-launch path (and the round-1 structure).
-template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
+template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4, bool F16 = ffn_f16<C>()>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void ffn_fused_kernel(
     const bf16* __restrict__ A, const char* __restrict__ w1img, const char* __restrict__ w2img,
     const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ ls,
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     const unsigned lds_w1 = __builtin_amdgcn_readfirstlane(lds_addr(w1ring)), lds_w2 = __builtin_amdgcn_readfirstlane(lds_addr(w2ring));
 
     for (int i = tid; i < HID / 4; i += WAVES * 64)
-        *(f32x4*)&lb1[i * 4] = *(const f32x4*)&b1[i * 4] * (ffn_f16<C>() ? 0.25f : 1.0f);          // half-precision form: GEMM1 delivers x / 4
+        *(f32x4*)&lb1[i * 4] = *(const f32x4*)&b1[i * 4] * (F16 ? 0.25f : 1.0f);          // half-precision form: GEMM1 delivers x / 4
 
     // per-lane fragment pointers (ring slot 0), see ffn_iter
     const char* w1p[C / 48];
@@ -401,15 +401,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 #define FFN_SYNC() ffn_wait_dma(); __syncthreads()
 #define FFN_B1PREV(cur) ((cur) == lb1 ? lb1 + (NCH - 1) * 32 : (cur) - 32)     // b1 of the chunk before `cur` (cyclic)
     FFN_SYNC();
-    ffn_iter<C, NB, WAVES, true, false, false, !(VAR & 1), VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(0));
+    ffn_iter<C, NB, WAVES, true, false, false, !(VAR & 1), VAR, PF, F16>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(0));
     FFN_SYNC();
-    ffn_iter<C, NB, WAVES, true, true, false, !(VAR & 1), VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + 32, FFN_B1PREV(lb1 + 32), half, FFN_DMA_ARGS(1));
+    ffn_iter<C, NB, WAVES, true, true, false, !(VAR & 1), VAR, PF, F16>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + 32, FFN_B1PREV(lb1 + 32), half, FFN_DMA_ARGS(1));
 #pragma unroll 1
     for (int t = 2; t < NCH; t += 2) {
         FFN_SYNC();                  // even t: S(t) -> s0, GELU(s1) -> p1, GEMM2 reads p0
-        ffn_iter<C, NB, WAVES, true, true, true, !(VAR & 1), VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1 + t * 32, FFN_B1PREV(lb1 + t * 32), half, FFN_DMA_ARGS(t));
+        ffn_iter<C, NB, WAVES, true, true, true, !(VAR & 1), VAR, PF, F16>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1 + t * 32, FFN_B1PREV(lb1 + t * 32), half, FFN_DMA_ARGS(t));
         FFN_SYNC();                  // odd t:  S(t) -> s1, GELU(s0) -> p0, GEMM2 reads p1
-        ffn_iter<C, NB, WAVES, true, true, true, !(VAR & 1), VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + (t + 1) * 32, FFN_B1PREV(lb1 + (t + 1) * 32), half, FFN_DMA_ARGS(t + 1));
+        ffn_iter<C, NB, WAVES, true, true, true, !(VAR & 1), VAR, PF, F16>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1 + (t + 1) * 32, FFN_B1PREV(lb1 + (t + 1) * 32), half, FFN_DMA_ARGS(t + 1));
     }
     // the residual tile of X is fetched now, coalesced like A^T above (the A^T registers are dead from here on), so that
     // its HBM latency hides behind the last two pipeline iterations instead of stalling the epilogue
@@ -434,9 +434,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     }
     }
     FFN_SYNC();                      // t = NCH (even): GELU(S(NCH-1) in s1) -> p1, GEMM2(chunk NCH-2) reads p0; DMA W2[NCH-1]
-    ffn_iter<C, NB, WAVES, false, true, true, !(VAR & 1), VAR, PF>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
+    ffn_iter<C, NB, WAVES, false, true, true, !(VAR & 1), VAR, PF, F16>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
     FFN_SYNC();                      // t = NCH + 1: GEMM2(chunk NCH-1) reads p1
-    ffn_iter<C, NB, WAVES, false, false, true, false, VAR, PF>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
+    ffn_iter<C, NB, WAVES, false, false, true, false, VAR, PF, F16>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
 #undef FFN_DMA_ARGS
 
     // ---- epilogue.  The accumulators are in MFMA layout (lane = row li, 4 consecutive channels n0 = nf*32 + 8q + 4*half per
@@ -508,7 +508,7 @@ template <typename K> static hipError_t ffn_set_lds(K kernel, size_t shmem, bool
     return e;
 }
 
-template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4>
+template <int C, int NB, int WAVES, int VAR = 0, int PF = 3, int OCC = WAVES / 4, bool F16 = ffn_f16<C>()>
 static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, const char* w2img, const float* b1,
                              const float* b2, const float* ls, bf16* X, int M)
 {
@@ -516,12 +516,12 @@ static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, c
     const int nwg = (M + ROWS - 1) / ROWS;
     const size_t shmem = (size_t)4 * 64 * C + (size_t)4 * C * 4 + 256;
     static bool attr_set[64];                // the attribute is per device
-    hipError_t e = ffn_set_lds(ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>, shmem, attr_set);
+    hipError_t e = ffn_set_lds(ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC, F16>, shmem, attr_set);
     if (e != hipSuccess) return e;
     // (Round 3 tried starting half of the first generation of workgroups 6-45 us late so that the memory phases of one half of the chip fall
     // into the chunk loops of the other: no gain in sustained operation - 354 / 369 / 493 us per launch at C = 384 / 192 / 96 with or
     // without, the whole step 26.83 -> 26.84 .. 27.4 ms - back-to-back launches already overlap at their tails; profiles/r03_ffn_stagger.log.)
-    hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
+    hipLaunchKernelGGL((ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC, F16>), dim3(nwg), dim3(WAVES * 64), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
     return hipGetLastError();
 }
 
@@ -558,11 +558,13 @@ static uint16_t to_f16(float f)       // round-to-nearest-even, subnormals kept,
     return (uint16_t)(sign | bits);
 }
 
-extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uint16_t* w1img, uint16_t* w2img)
+// precision: FVHD_FFN_HALF (0) = the half-precision hidden activation (gelu_half16; the default), FVHD_FFN_BF16 (1) = the f32 GELU with a
+// bf16 hidden operand (no range limit: for blocks whose fc1 output can exceed the f16 form's 262 016, fvhd_audit_ranges)
+extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uint16_t* w1img, uint16_t* w2img, int precision)
 {
-    if (!fvhd_ffn_fused_supported(C)) return 1;
+    if (!fvhd_ffn_fused_supported(C) || precision < 0 || precision > 1) return 1;
     // half-precision form (see gelu_half16): W1 carries the factor 1/4 (exact in bf16), W2 is f16(4 W2)
-    const bool f16 = C == 384 ? ffn_f16<384>() : C == 192 ? ffn_f16<192>() : ffn_f16<96>();
+    const bool f16 = precision == 0;
     const float s1 = f16 ? 0.25f : 1.0f;
     const int HID = 4 * C, NCH = HID / 32, CHE = 32 * C;   // bf16 elements per chunk image
     for (int i = 0; i < (NCH + 1) * CHE; ++i) w1img[i] = 0;
@@ -589,8 +591,11 @@ extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uin
 }
 
 // A [M,C] bf16; w1img / w2img from fvhd_ffn_pack_host (device copies); b1 [4C], b2 [C], ls [C] fp32; X [M,C] in/out.
+// largest |4 * W2| the half-precision form can hold: a block whose fc2 weights exceed it must be packed with FVHD_FFN_BF16
+extern "C" float fvhd_ffn_half_w2_limit(void) { return 65504.0f / 4.0f; }
+
 extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* w1img, const float* b1, const void* w2img,
-                                     const float* b2, const float* ls, void* X, int M, int C)
+                                     const float* b2, const float* ls, void* X, int M, int C, int precision)
 {
     const bf16* a = (const bf16*)A;
     const char* w1 = (const char*)w1img;
@@ -616,6 +621,13 @@ extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* 
     if (C == 384) { FFN_V(384, 1) } else if (C == 192) { FFN_V(192, 2) } else if (C == 96) { FFN_V(96, 3) }
 #undef FFN_V
 #endif
+    if (precision == 1) {      // f32 GELU, bf16 hidden operand (the round-1..3a kernel): no range limit on the fc1 output
+        if (C == 384) e = launch_ffn<384, 1, 4, 0, 3, 1, false>(st, a, w1, w2, b1, b2, ls, x, M);
+        else if (C == 192) e = launch_ffn<192, 1, 4, 0, 3, 2, false>(st, a, w1, w2, b1, b2, ls, x, M);
+        else if (C == 96) e = launch_ffn<96, 1, 4, 0, 3, 3, false>(st, a, w1, w2, b1, b2, ls, x, M);
+        return (int)e;
+    }
+    if (precision != 0) return (int)e;
     if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
     else if (C == 192) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
     // C = 96: 152 registers since the epilogue offsets stopped being hoisted -> three workgroups (waves) per SIMD: the kernel is

@@ -28,11 +28,12 @@ int fvhd_launch_stem_conv(hipStream_t, const void*, int, void*, const float*, co
 int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, const float*, const float*, const float*,
                         void*, int, int, int, int, int);
 int fvhd_launch_cast_to_bf16(hipStream_t, const void*, int, void*, long);
-int fvhd_launch_ffn_fused(hipStream_t, const void*, const void*, const float*, const void*, const float*, const float*, void*, int, int);
+int fvhd_launch_ffn_fused(hipStream_t, const void*, const void*, const float*, const void*, const float*, const float*, void*, int, int, int);
+float fvhd_ffn_half_w2_limit(void);
 int fvhd_ffn_fused_supported(int);
 int fvhd_launch_splice(hipStream_t, const long*, const int*, const int*, const long*, const long*, const void*, const void*, void*,
                        unsigned char*, long*, long*, int, int, int, int, long, long, int, int);
-int fvhd_ffn_pack_host(int, const float*, const float*, uint16_t*, uint16_t*);
+int fvhd_ffn_pack_host(int, const float*, const float*, uint16_t*, uint16_t*, int);
 }
 
 namespace {
@@ -97,7 +98,9 @@ struct Packer {          // builds the packed weight image on the host; offsets 
 
 struct DwW { size_t w = 0, b = 0; int K = 0; };                    // taps fp32 [K*K][Cout], bias fp32 [Cout]
 struct GemmW { size_t w = 0, b = 0; int N = 0, K = 0; bool has_bias = false; };
-struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; size_t w1img = 0, w2img = 0; bool fused = false; };   // w?img: chunk images of the fused kernel
+// w?img: chunk images of the fused kernel in its two precisions ([0] FVHD_FFN_HALF: W1 / 4 in bf16, 4 W2 in f16; [1] FVHD_FFN_BF16);
+// precision: which one this block runs (fvhd_set_ffn_precision / fvhd_audit_ranges; FVHD_FFN_BF16 from the start if |4 W2| would overflow f16)
+struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; size_t w1img[2] = {0, 0}, w2img[2] = {0, 0}; bool fused = false; int precision = FVHD_FFN_HALF; };
 struct RepBlockW { DwW mixer; FfnW ffn; };
 struct AttnBlockW { size_t ln_w = 0, ln_b = 0, ls1 = 0; GemmW qkv, proj; FfnW ffn; };
 struct DownW { DwW dw; GemmW pw; };
@@ -145,6 +148,9 @@ struct fvhd_ctx {
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
     bool use_fused_stem = true;  // FVHD_FUSED_STEM=0: stem[0] and stem[1] as two launches through a [B,R/2,R/2,96] HBM tensor
     int batch_invariant = 0;     // fvhd_set_batch_invariant: kernel choice by image shape only (bit-identical rows in any batch)
+    // fvhd_audit_ranges: while set, every ConvFFN also runs its fc1 as a plain GEMM (bias, no GELU) and reduces max |fc1 out| into
+    // audit_dev[step] (fp32 bit patterns of non-negative values, ordered as unsigned integers)
+    unsigned* audit_dev = nullptr;
     // hipGraph replay of the interior steps (fvhd_set_graph / FVHD_GRAPH=1): ~170 launches become one hipGraphLaunch.
     // The stem (reads the caller's images) and the head (writes the caller's buffer) stay outside the graph, so a cached
     // graph only holds library-owned pointers (workspace, packed weights) and is valid for any caller buffers.
@@ -251,10 +257,15 @@ bool pack_ffn(fvhd_ctx* c, Packer& pk, const std::string& p, const std::string& 
         const HostTensor* w2 = find(c, p + ".convffn.fc2.weight", {C, 4 * C, 1, 1});
         if (!w1 || !w2) return false;
         const size_t che = (size_t)32 * C, nch = (size_t)4 * C / 32;
-        out->w1img = pk.reserve((nch + 1) * che * 2);
-        out->w2img = pk.reserve(nch * che * 2);     // (reserve may move buf: take the pointers after both calls)
-        if (fvhd_ffn_pack_host(C, w1->data.data(), w2->data.data(), (uint16_t*)(pk.buf.data() + out->w1img),
-                               (uint16_t*)(pk.buf.data() + out->w2img))) return false;
+        for (int pr = 0; pr < 2; ++pr) {
+            out->w1img[pr] = pk.reserve((nch + 1) * che * 2);
+            out->w2img[pr] = pk.reserve(nch * che * 2);     // (reserve may move buf: take the pointers after both calls)
+            if (fvhd_ffn_pack_host(C, w1->data.data(), w2->data.data(), (uint16_t*)(pk.buf.data() + out->w1img[pr]),
+                                   (uint16_t*)(pk.buf.data() + out->w2img[pr]), pr)) return false;
+        }
+        float w2max = 0.f;
+        for (float v : w2->data) w2max = fmaxf(w2max, fabsf(v));
+        out->precision = (w2max < fvhd_ffn_half_w2_limit()) ? FVHD_FFN_HALF : FVHD_FFN_BF16;     // f16(4 W2) must stay finite
         out->fused = true;
     }
     return pack_vec(c, pk, ls_key, {C, 1, 1}, &out->ls);
@@ -366,6 +377,29 @@ struct Scope {   // brackets one launch with events when profiling is on
         if (_e) return hip_fail(what, (hipError_t)_e);                        \
     } while (0)
 
+// max |x| over n8 * 8 bf16 values, as the fp32 bit pattern of a non-negative number (unsigned order = numeric order; Inf and NaN sort
+// above every finite value, so an overflow anywhere in the tensor surfaces in the result)
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t* __restrict__ x, long n8, unsigned* __restrict__ out)
+{
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const uint4 v = *(const uint4*)(x + i * 8);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned lo = w[k] & 0x7fffu, hi = (w[k] >> 16) & 0x7fffu;
+            m = m > lo ? m : lo;
+            m = m > hi ? m : hi;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = m > o ? m : o;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m << 16);
+}
+
 int run_dw(fvhd_ctx* c, hipStream_t st, int cls, const DwW& w, const void* x, void* y, int B, int H, int W, int Cin,
            int stride, int mult, int gelu)
 {
@@ -388,18 +422,25 @@ int run_gemm(fvhd_ctx* c, hipStream_t st, int cls, const char* wbase, const Gemm
 constexpr int kFusedFfnMinRows = 24576;
 
 // ConvFFN + layer scale + residual, in place on x (mci.py:1106-1109 / 1185-1188 second line)
-int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, int B, int H, int Wd, int C)
+int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, int B, int H, int Wd, int C, int step)
 {
     const int M = B * H * Wd;
     int e;
     if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0))) return e;
+    if (c->audit_dev) {          // range audit: fc1 + bias as a plain GEMM into the hidden buffer, max |.| of it into this step's slot
+        if ((e = run_gemm(c, st, C_FC1, c->wdev, f.fc1, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_BIAS))) return e;
+        const long n8 = (long)M * 4 * C / 8;
+        hipLaunchKernelGGL(absmax_bf16_kernel, dim3((unsigned)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096)), dim3(256), 0, st,
+                           (const uint16_t*)w.H, n8, c->audit_dev + step);
+        CHECK_LAUNCH((int)hipGetLastError(), "absmax launch");
+    }
     // The fused kernel gives one workgroup 128 rows and walks the whole hidden dimension serially (48 chunks at C = 384: ~60 us
     // however few rows there are).  Below ~0.75 workgroups per CU the two tiled GEMMs (hundreds of tiles even at M = 4096) finish
     // sooner: B = 1 at 1024^2 runs stages 2 / 3 (M = 16384 / 4096) this way, 4.27 -> 3.4 ms per image.
     if (f.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows)) {
         Scope s(c, st, C_FFN);
-        CHECK_LAUNCH(fvhd_launch_ffn_fused(st, w.A, c->wdev + f.w1img, c->wp<float>(f.fc1.b), c->wdev + f.w2img,
-                                           c->wp<float>(f.fc2.b), c->wp<float>(f.ls), x, M, C),
+        CHECK_LAUNCH(fvhd_launch_ffn_fused(st, w.A, c->wdev + f.w1img[f.precision], c->wp<float>(f.fc1.b), c->wdev + f.w2img[f.precision],
+                                           c->wp<float>(f.fc2.b), c->wp<float>(f.ls), x, M, C, f.precision),
                      "fused ffn launch");
         return 0;
     }
@@ -440,7 +481,7 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
         const RepBlockW& blk = m.rep[sp.stage][sp.idx];
         if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0))) return e;
         std::swap(X, T);
-        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C);
+        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, (int)(&sp - c->m.steps.data()));
     }
     case S_ATT: {    // AttentionBlock (mci.py:1185-1188)
         const AttnBlockW& blk = m.att[sp.stage - 3][sp.idx];
@@ -455,7 +496,7 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
             CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C), "attention launch");
         }
         if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID))) return e;
-        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C);
+        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, (int)(&sp - c->m.steps.data()));
     }
     case S_DOWN: {   // PatchEmbed (mci.py:739-741)
         const DownW& d = m.down[sp.stage];
@@ -837,6 +878,80 @@ int fvhd_set_batch_invariant(fvhd_ctx* c, int on)
     return 0;
 }
 
+static FfnW* ffn_of_step(fvhd_ctx* c, int step)
+{
+    if (!c || !c->finalized || step < 0 || step >= (int)c->m.steps.size()) return nullptr;
+    const Step& sp = c->m.steps[step];
+    if (sp.kind == S_REP) return &c->m.rep[sp.stage][sp.idx].ffn;
+    if (sp.kind == S_ATT) return &c->m.att[sp.stage - 3][sp.idx].ffn;
+    return nullptr;
+}
+
+int fvhd_get_ffn_precision(const fvhd_ctx* c, int step)
+{
+    const FfnW* f = ffn_of_step(const_cast<fvhd_ctx*>(c), step);
+    return (f && f->fused) ? f->precision : -1;      // -1: this step has no fused ConvFFN (its hidden tensor is bf16 in HBM: no f16 anywhere)
+}
+
+int fvhd_set_ffn_precision(fvhd_ctx* c, int step, int precision)
+{
+    FfnW* f = ffn_of_step(c, step);
+    if (!f || !f->fused) return fail("fvhd_set_ffn_precision: step " + std::to_string(step) + " has no fused ConvFFN");
+    if (precision != FVHD_FFN_HALF && precision != FVHD_FFN_BF16) return fail("fvhd_set_ffn_precision: precision must be FVHD_FFN_HALF or FVHD_FFN_BF16");
+    if (f->precision != precision) {
+        FVHD_ON_DEVICE(c);
+        (void)hipDeviceSynchronize();
+        clear_graphs(c);                     // cached graphs hold the other kernel and the other weight images
+        f->precision = precision;
+    }
+    return 0;
+}
+
+// Range audit of the fused ConvFFN's half-precision hidden activation (include/fvhd.h).  One eager pass over `images` with the fc1 output
+// of every ConvFFN materialised and reduced to its max |.|; host-synchronising, never inside a stream capture.
+int fvhd_audit_ranges(fvhd_ctx* c, const void* images, int img_dtype, int batch, float switch_above, float* max_abs_out, int* n_switched,
+                      fvhd_stream_t stream)
+{
+    if (!c || !images) return fail("fvhd_audit_ranges: NULL argument");
+    if (img_dtype < 0 || img_dtype > 2) return fail("fvhd_audit_ranges: bad dtype");
+    FVHD_ON_DEVICE(c);
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail("fvhd_audit_ranges: not during stream capture (it reads its result back)");
+    int e = prepare(c, batch, st);
+    if (e) return e;
+    const int n = (int)c->m.steps.size();
+    unsigned* dev = nullptr;
+    hipError_t he = hipMalloc((void**)&dev, (size_t)n * 4);
+    if (he != hipSuccess) return hip_fail("hipMalloc(audit)", he);
+    he = hipMemsetAsync(dev, 0, (size_t)n * 4, st);
+    const Ws w = carve(c, c->ws, c->ws_batch, c->ws_hidden);
+    char *X = w.X, *T = w.T;
+    c->audit_dev = dev;
+    if (he == hipSuccess) e = run_range(c, st, 0, n - 1, w, batch, X, T, images, img_dtype, w.tok, FVHD_BF16);   // tokens land in the workspace
+    c->audit_dev = nullptr;
+    std::vector<float> host((size_t)n, 0.f);
+    if (he == hipSuccess && !e) he = hipMemcpyAsync(host.data(), dev, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess && !e) he = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (e) return e;
+    if (he != hipSuccess) return hip_fail("fvhd_audit_ranges", he);
+    int switched = 0;
+    for (int i = 0; i < n; ++i) {
+        FfnW* f = ffn_of_step(c, i);
+        // !(x <= limit) also catches NaN (an Inf / NaN in the fc1 output sorts above every finite value in the reduction)
+        if (f && f->fused && switch_above > 0.f && !(host[i] <= switch_above) && f->precision != FVHD_FFN_BF16) {
+            f->precision = FVHD_FFN_BF16;
+            ++switched;
+        }
+    }
+    if (switched) clear_graphs(c);
+    if (max_abs_out) memcpy(max_abs_out, host.data(), (size_t)n * 4);
+    if (n_switched) *n_switched = switched;
+    return 0;
+}
+
 int fvhd_profile_enable(fvhd_ctx* c, int on)
 {
     if (!c) return fail("fvhd_profile_enable: ctx is NULL");
@@ -958,9 +1073,10 @@ int fvhd_op_preprocess(fvhd_stream_t st, const void* src, int src_h, int src_w, 
 }
 
 int fvhd_op_ffn_fused(fvhd_stream_t st, const void* A, const void* w1img, const float* b1, const void* w2img, const float* b2,
-                      const float* ls, void* X, int M, int C)
+                      const float* ls, void* X, int M, int C, int precision)
 {
-    int e = fvhd_launch_ffn_fused((hipStream_t)st, A, w1img, b1, w2img, b2, ls, X, M, C);
+    if (precision != FVHD_FFN_HALF && precision != FVHD_FFN_BF16) return fail("fvhd_op_ffn_fused: precision must be FVHD_FFN_HALF or FVHD_FFN_BF16");
+    int e = fvhd_launch_ffn_fused((hipStream_t)st, A, w1img, b1, w2img, b2, ls, X, M, C, precision);
     return e ? hip_fail("fvhd_op_ffn_fused", (hipError_t)e) : 0;
 }
 
@@ -975,11 +1091,11 @@ int fvhd_op_splice(fvhd_stream_t st, const int64_t* ids, const int32_t* start, c
     return e ? hip_fail("fvhd_op_splice", (hipError_t)e) : 0;
 }
 
-int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img)
+int fvhd_ffn_pack(int C, const float* host_fc1, const float* host_fc2, void* host_w1img, void* host_w2img, int precision)
 {
     if (!host_fc1 || !host_fc2 || !host_w1img || !host_w2img) return fail("fvhd_ffn_pack: NULL argument");
-    if (fvhd_ffn_pack_host(C, host_fc1, host_fc2, (uint16_t*)host_w1img, (uint16_t*)host_w2img))
-        return fail("fvhd_ffn_pack: the fused ConvFFN kernel exists for C in {96, 192, 384}");
+    if (fvhd_ffn_pack_host(C, host_fc1, host_fc2, (uint16_t*)host_w1img, (uint16_t*)host_w2img, precision))
+        return fail("fvhd_ffn_pack: the fused ConvFFN kernel exists for C in {96, 192, 384}, precision FVHD_FFN_HALF / FVHD_FFN_BF16");
     return 0;
 }
 

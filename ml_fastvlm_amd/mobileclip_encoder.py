@@ -109,6 +109,14 @@ class MobileCLIPVisionTower(nn.Module):
         self.hip_graph = None if graph is None else bool(graph)
         inv = getattr(args, "mm_vision_batch_invariant", None)
         self.batch_invariant = None if inv is None else bool(inv)
+        # precision of the fused ConvFFN's hidden activation (include/fvhd.h "precision of the fused ConvFFN's hidden activation"):
+        # "half" (default; gelu(x)/4 in IEEE half - saturates beyond |fc1 output| = 262 016) or "bf16" (every block on the f32-GELU /
+        # bf16-operand form of the same kernel: no range limit, a few % slower).  Per block: `audit_ranges()` below.
+        prec = getattr(args, "mm_vision_ffn_precision", None) or "half"
+        if prec not in ("half", "bf16"):
+            raise ValueError(f"mm_vision_ffn_precision must be 'half' or 'bf16', got {prec!r}")
+        self.ffn_precision = prec
+        self._ffn_bf16_steps = set()            # steps an audit moved to the bf16 form (re-applied whenever the weights are re-packed)
         # expected batch size (sizes the library's workspace up front; it grows geometrically when a larger batch arrives)
         self._batch_hint = max(1, int(getattr(args, "mm_vision_max_batch", 1) or 1))
         self._ctx: Optional[_lib.Context] = None
@@ -150,6 +158,7 @@ class MobileCLIPVisionTower(nn.Module):
 
     def _mark_dirty(self) -> None:
         self._dirty = True
+        self._ffn_bf16_steps = set()            # new weights: an earlier range audit says nothing about them
 
     def _apply(self, fn, *a, **kw):
         # .to() / .half() / .cuda(): parameter storage (and possibly values, through a dtype cast) changes
@@ -178,11 +187,48 @@ class MobileCLIPVisionTower(nn.Module):
                     self._ctx.set_tensor(k, v)
             self._ctx.finalize()
             self._dirty = False
+            self._apply_ffn_precision(self._ctx)
         if self.hip_graph is not None:
             self._ctx.set_graph(self.hip_graph)
         if self.batch_invariant is not None:
             self._ctx.set_batch_invariant(self.batch_invariant)
         return self._ctx
+
+    def _apply_ffn_precision(self, ctx) -> None:
+        for step in range(len(ctx.steps())):
+            if ctx.ffn_precision(step) >= 0 and (self.ffn_precision == "bf16" or step in self._ffn_bf16_steps):
+                ctx.set_ffn_precision(step, _lib.FFN_BF16)
+
+    def audit_ranges(self, images: torch.Tensor, switch_above: float = 65504.0):
+        """Range audit of the half-precision hidden activation of the fused ConvFFN kernels (no counterpart in the reference, whose bf16 /
+        fp32 hidden tensor has no such limit).  Run it ONCE per checkpoint on a calibration batch of real, preprocessed images: every
+        ConvFFN's fc1 output is materialised and reduced to max |.|; a fused block whose maximum exceeds `switch_above` (default 65 504: a
+        factor 4 below the 262 016 where gelu(x)/4 saturates in f16) - or is not finite - is switched to the bf16-operand form of the
+        kernel for all later calls of this tower (remembered across `.to()` / re-packing; a `load_state_dict` clears it).  Returns
+        [{"step", "kind", "stage", "block", "max_abs_fc1", "precision", "switched"}] for every step that has a ConvFFN and warns when
+        anything was switched.  Synchronises."""
+        with torch.no_grad():
+            images = self._check_images(images)
+            ctx = self._context()
+            self._grow(ctx, images.shape[0])
+            before = [ctx.ffn_precision(i) for i in range(len(ctx.steps()))]
+            maxes, switched = ctx.audit_ranges(images, switch_above)
+        report = []
+        for i, (kind, stage, block, *_rest) in enumerate(ctx.steps()):
+            if kind not in ("repmixer_block", "attention_block"):
+                continue
+            now = ctx.ffn_precision(i)
+            if now == _lib.FFN_BF16 and before[i] == _lib.FFN_HALF:
+                self._ffn_bf16_steps.add(i)
+            report.append({"step": i, "kind": kind, "stage": stage, "block": block, "max_abs_fc1": maxes[i],
+                           "precision": {-1: "two GEMMs (bf16 hidden tensor in HBM)", 0: "half", 1: "bf16"}[now],
+                           "switched": now == _lib.FFN_BF16 and before[i] == _lib.FFN_HALF})
+        if switched:
+            import warnings
+            hot = [(r["step"], r["max_abs_fc1"]) for r in report if r["switched"]]
+            warnings.warn(f"ml_fastvlm_amd: {switched} ConvFFN block(s) exceed |fc1 output| = {switch_above:g} on the calibration batch and now run "
+                          f"the bf16-operand form of the fused kernel (step, max): {hot}")
+        return report
 
     # The ctypes handle is process-local state, not model state: copies / pickles of a tower start without a context and
     # re-pack their weights on first use (copy.deepcopy of a model after its first forward used to fail on the handle).

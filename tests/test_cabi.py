@@ -73,8 +73,8 @@ def test_ffn_pack_layout(lib, C):
     i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
     i2 = torch.empty(nch * che, dtype=torch.bfloat16)
     vp = ctypes.c_void_p
-    assert lib.fvhd_ffn_pack(C, vp(w1.data_ptr()), vp(w2.data_ptr()), vp(i1.data_ptr()), vp(i2.data_ptr())) == 0
-    assert lib.fvhd_ffn_pack(128, vp(w1.data_ptr()), vp(w2.data_ptr()), vp(i1.data_ptr()), vp(i2.data_ptr())) != 0
+    assert lib.fvhd_ffn_pack(C, vp(w1.data_ptr()), vp(w2.data_ptr()), vp(i1.data_ptr()), vp(i2.data_ptr()), 0) == 0
+    assert lib.fvhd_ffn_pack(128, vp(w1.data_ptr()), vp(w2.data_ptr()), vp(i1.data_ptr()), vp(i2.data_ptr()), 0) != 0
     # the half-precision form of the kernel (include/fvhd.h): W1 carries the factor 1/4 (exact in bf16), W2 is IEEE half of 4 W2
     i1 = i1.float() * 4.0
     i2 = i2.view(torch.float16).float() / 4.0

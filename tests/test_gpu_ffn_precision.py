@@ -1,0 +1,100 @@
+"""Run-time precision of the fused ConvFFN's hidden activation.
+
+The fused kernel keeps gelu(fc1) / 4 in IEEE half: better than bf16 inside its range, but |fc1 output| > 262 016 saturates where the
+reference's bf16 / fp32 hidden tensor (mci.py:922-926) carries on.  Both forms of the kernel are compiled in; `fvhd_audit_ranges` (here
+through `MobileCLIPVisionTower.audit_ranges`) finds the blocks a checkpoint drives out of range on a calibration batch and switches
+exactly those to the bf16-operand form.  This test builds such a checkpoint: one hidden unit of ONE block (stage 1, block 3) is driven
+to 2^19 = 524 288 through its fc1 bias, with a small fc2 column so that the block's output stays O(1).
+
+STATED TOLERANCE after the switch: the whole-tower budget of the mild weight profile, rel-L2 <= 1.5e-2, cosine >= 0.9998
+against the fp32 CPU oracle; before it the saturated block must be visibly worse (>= 3x)."""
+import warnings
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import ml_fastvlm_amd as fv
+from ml_fastvlm_amd import _lib, synth
+from oracle import fastvithd_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HOT_BLOCK, HOT_UNIT, HOT_VALUE = "network.2.3", 77, 524288.0
+
+
+def _hot_state_dict():
+    sd = synth.synthetic_state_dict(1234, "mild")
+    sd[f"{HOT_BLOCK}.convffn.fc1.bias"][HOT_UNIT] = HOT_VALUE
+    sd[f"{HOT_BLOCK}.convffn.fc2.weight"][:, HOT_UNIT] *= 2.0 ** -12
+    return sd
+
+
+def _metrics(got, want):
+    a, b = got.double().cpu().flatten(), want.double().cpu().flatten()
+    return ((a - b).norm() / b.norm()).item(), torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+
+
+def test_audit_finds_the_saturating_block_and_the_switch_restores_parity():
+    sd = _hot_state_dict()
+    x = synth.synthetic_images(2, 256, seed=5)
+    want = O.tower_forward(x, sd)
+    # batch_invariant: the fused ConvFFN kernels run whatever the batch (at 256 px the default selection would take two GEMMs)
+    tower = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_batch_invariant=True))
+    tower.vision_tower.model.load_state_dict(sd, strict=True)
+    tower = tower.to(DEV, torch.bfloat16)
+    xd = x.to(DEV)
+    before = tower(xd).float().cpu()
+    rel0, cos0 = _metrics(before, want)
+
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        report = tower.audit_ranges(xd)
+    fused = [r for r in report if r["precision"] in ("half", "bf16")]
+    assert len(fused) == 38, "stages 0-2: 2 + 12 + 24 fused ConvFFN blocks"
+    hot = [r for r in report if r["switched"]]
+    assert len(hot) == 1 and (hot[0]["stage"], hot[0]["block"]) == (1, 3), hot
+    assert hot[0]["max_abs_fc1"] >= 0.99 * HOT_VALUE and hot[0]["precision"] == "bf16"
+    assert all(r["max_abs_fc1"] < 1000.0 for r in report if not r["switched"]), "the mild profile keeps every other fc1 output O(10)"
+    assert any("ConvFFN block" in str(w.message) for w in caught), "a switch is reported as a warning"
+
+    after = tower(xd).float().cpu()
+    rel1, cos1 = _metrics(after, want)
+    print(f"fc1 output up to {hot[0]['max_abs_fc1']:.0f} in {HOT_BLOCK}: half-precision hidden rel-L2 {rel0:.3e} cos {cos0:.6f}  ->  "
+          f"after the audit (that block on the bf16-operand form) rel-L2 {rel1:.3e} cos {cos1:.6f}")
+    assert rel1 <= 1.5e-2 and cos1 >= 0.9998, (rel1, cos1)
+    assert rel0 >= 3.0 * rel1, "the saturation should have been visible before the switch"
+
+    # the choice survives a re-pack of the same weights (.to()) ...
+    tower = tower.to(DEV, torch.float16).to(DEV, torch.bfloat16)
+    again = tower(xd).float().cpu()
+    assert torch.equal(again, after)
+    ctx = tower._context()
+    assert [i for i in range(len(ctx.steps())) if ctx.ffn_precision(i) == _lib.FFN_BF16] == [hot[0]["step"]]
+    # ... and is dropped by new weights, whose ranges nobody has audited yet
+    tower.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234, "mild"), strict=True)
+    ctx = tower._context()
+    assert all(ctx.ffn_precision(i) != _lib.FFN_BF16 for i in range(len(ctx.steps())))
+
+
+def test_every_block_on_the_bf16_form_by_configuration():
+    """mm_vision_ffn_precision='bf16': all 38 fused blocks on the f32-GELU / bf16-operand kernel; the tower stays inside the mild budget
+    (rel-L2 <= 1e-2, cosine >= 0.9999 - SURVEY.md 8c) and close to the default form."""
+    sd = synth.synthetic_state_dict(1234, "mild")
+    x = synth.synthetic_images(2, 256, seed=6)
+    want = O.tower_forward(x, sd)
+    outs = {}
+    for prec in ("half", "bf16"):
+        t = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_batch_invariant=True,
+                                                                          mm_vision_ffn_precision=prec))
+        t.vision_tower.model.load_state_dict(sd, strict=True)
+        t = t.to(DEV, torch.bfloat16)
+        outs[prec] = t(x.to(DEV)).float().cpu()
+        ctx = t._context()
+        n_bf16 = sum(ctx.ffn_precision(i) == _lib.FFN_BF16 for i in range(len(ctx.steps())))
+        assert n_bf16 == (38 if prec == "bf16" else 0)
+        rel, cos = _metrics(outs[prec], want)
+        print(f"mm_vision_ffn_precision={prec}: vs fp32 oracle rel-L2 {rel:.3e} cos {cos:.6f}")
+        assert rel <= 1e-2 and cos >= 0.9999, (prec, rel, cos)
+    with pytest.raises(ValueError):
+        fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_ffn_precision="fp8"))

@@ -9,6 +9,8 @@ import sys
 
 import torch
 
+FFN_PREC = int(__import__('os').environ.get('FVHD_FFN_PREC', '0'))      # 0 = FFN_HALF (default), 1 = FFN_BF16
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ml_fastvlm_amd import _lib  # noqa: E402
@@ -59,12 +61,12 @@ def bench_ffn(B=32):
         nch, che = HID // 32, 32 * Cc
         i1 = torch.empty((nch + 1) * che, dtype=torch.bfloat16)
         i2 = torch.empty(nch * che, dtype=torch.bfloat16)
-        _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2)))
+        _lib.check(lib.fvhd_ffn_pack(Cc, p(W1), p(W2), p(i1), p(i2), FFN_PREC))
         i1, i2 = i1.to(DEV), i2.to(DEV)
         b1 = torch.randn(HID, generator=g).to(DEV) * 0.1
         b2 = torch.randn(Cc, generator=g).to(DEV) * 0.1
         ls = torch.full((Cc,), 0.01, device=DEV)
-        t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc)))
+        t = timeit(lambda: _lib.check(lib.fvhd_op_ffn_fused(stream(), p(A), p(i1), p(b1), p(i2), p(b2), p(ls), p(X), M, Cc, FFN_PREC)))
         fl, by = 16.0 * M * Cc * Cc, 6.0 * M * Cc
         print(f"ffn_fused C={Cc:4d} M={M:8d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.1f} GB/s (algorithmic)")
 
