@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--hidden", type=int, default=896, help="LLM hidden size of the projector (896 = Qwen2-0.5B)")
     ap.add_argument("--graph", action="store_true", help="hipGraph replay of the tower's interior launches (fvhd_set_graph)")
+    ap.add_argument("--attn-fp8", action="store_true", help="e4m3 MFMA operands in the attention cores (BASELINE.json configs[4] as named; opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tower-only", action="store_true", help="time the vision tower without the projector")
@@ -276,7 +277,8 @@ def main():
         return
 
     B, R, Hd = args.batch, args.res, args.hidden
-    tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{R}", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_hip_graph=args.graph))
+    tower = fv.MobileCLIPVisionTower(f"mobileclip_l_{R}", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_hip_graph=args.graph,
+                                                                          mm_vision_attention_fp8=True if args.attn_fp8 else None))
     tower.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234), strict=True)
     proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=Hd))
     proj.load_state_dict(synth.synthetic_projector_state_dict(Hd, 1234), strict=True)
@@ -340,7 +342,7 @@ def main():
                                f"batch={B}/GPU synthetic {R}x{R} bf16 images in [0,1), seeded synthetic weights, "
                                f"{('tokens all-gathered over RCCL ' + side + ' the projector') if multi else 'single GPU'}",
                    "global_batch": B * world, "image_size": R, "tokens_per_image": (R // 64) ** 2, "parallelism": f"dp{world}",
-                   "hip_graph": bool(args.graph), "attention_operands": "bf16",
+                   "hip_graph": bool(args.graph), "attention_operands": "e4m3" if args.attn_fp8 else "bf16",
                    **({"collective": f"all_gather_into_tensor over nccl (RCCL), world {world}", "gather_side": side} if multi else {})},
     }
 

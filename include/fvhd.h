@@ -139,6 +139,13 @@ int fvhd_run_steps(fvhd_ctx* ctx, int first, int last, const void* x_in, int bat
  * "layernorm", "attention", "head", "projector", "ffn_fused". */
 int fvhd_profile_enable(fvhd_ctx* ctx, int on);
 
+/* Precision option of the MHSA core (mci.py:670-679) for BASELINE.json configs[4] ("fp8 MFMA attention path"), OPT-IN:
+ * on != 0 runs QK^T and PV with OCP e4m3 operands (fvhd_op_attention_fp8) in every AttentionBlock of fvhd_encode /
+ * fvhd_run_steps; default 0 = bf16 operands (the parity path).  The reference has no such switch: its attention runs in
+ * the tower dtype (mobileclip_encoder.py:85).  Also settable with the environment variable FVHD_ATTN_FP8=1 at fvhd_create.
+ * Measured: no faster than bf16 on gfx950 (the non-scaled fp8 MFMA issues at the bf16 rate; DESIGN.md "fp8"). */
+int fvhd_set_attention_fp8(fvhd_ctx* ctx, int on);
+
 /* Kernel selection.  Default (0): every launch takes the fastest kernel for its shape INCLUDING the batch - below ~0.75 workgroups
  * per CU the depthwise 7x7 runs on the VALU kernel instead of the matrix-core one and ConvFFN as two tiled GEMMs instead of the
  * fused kernel (B = 1 at 1024^2: 4.3 -> 3.5 ms).  Results are then bit-identical for a given batch size (any order, any
@@ -177,6 +184,9 @@ int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const floa
 int fvhd_op_layernorm(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* b, int M, int C, float eps);
 /* MHSA core (mci.py:670-679): qkv [B*N,3C] bf16 -> out [B*N,C] bf16, head_dim 32. */
 int fvhd_op_attention(fvhd_stream_t stream, const void* qkv, void* out, int B, int N, int C);
+/* same, Q/K/V and P = exp(s - max) rounded to OCP e4m3 (RNE) as MFMA operands, fp32 accumulation and running maximum; the softmax
+ * denominator sums the same e4m3 P values that multiply V. */
+int fvhd_op_attention_fp8(fvhd_stream_t stream, const void* qkv, void* out, int B, int N, int C);
 /* stem[0] (mci.py:563-574): img [B,3,R,R] of dtype -> out [B,R/2,R/2,96] bf16; w fp32 [27][96] (k = ci*9+ky*3+kx). */
 int fvhd_op_stem_conv(fvhd_stream_t stream, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R);
 /* stem[0] + stem[1] in one launch (mci.py:563-586): img [B,3,R,R] of dtype -> out [B,R/4,R/4,96] bf16;

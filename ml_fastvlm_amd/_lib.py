@@ -50,6 +50,8 @@ def _declare(lib) -> None:
         "fvhd_op_gemm": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
         "fvhd_op_layernorm": (ci, [vp, vp, vp, vp, vp, ci, ci, cf]),
         "fvhd_op_attention": (ci, [vp, vp, vp, ci, ci, ci]),
+        "fvhd_op_attention_fp8": (ci, [vp, vp, vp, ci, ci, ci]),
+        "fvhd_set_attention_fp8": (ci, [vp, ci]),
         "fvhd_set_graph": (ci, [vp, ci]),
         "fvhd_set_batch_invariant": (ci, [vp, ci]),
         "fvhd_op_stem_conv": (ci, [vp, vp, ci, vp, vp, vp, ci, ci]),
@@ -197,6 +199,10 @@ class Context:
     def run_steps(self, first: int, last: int, x_in, x_out) -> None:
         check(load().fvhd_run_steps(self._h, first, last, ptr(x_in), x_in.shape[0], ptr(x_out), stream_ptr(x_in.device)),
               "fvhd_run_steps")
+
+    def set_attention_fp8(self, on: bool) -> None:
+        """e4m3 MFMA operands in the MHSA core (BASELINE.json configs[4], opt-in); default off = bf16 operands."""
+        check(load().fvhd_set_attention_fp8(self._h, int(bool(on))), "fvhd_set_attention_fp8")
 
     def set_batch_invariant(self, on: bool) -> None:
         """kernel choice by image shape only: an image gives the same bits in any batch (default off = fastest kernel per batch size)."""

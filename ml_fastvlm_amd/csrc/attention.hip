@@ -92,10 +92,25 @@ extern "C" int fvhd_launch_layernorm(hipStream_t st, const void* x, void* y, con
 #define ATT_QB (64 * ATT_QW)   // queries per workgroup
 #define ATT_VT_STRIDE 136  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
 
-// (Rounds 1-2 carried an e4m3 variant of this kernel for BASELINE.json configs[4] - Q, K, V and P rounded to OCP e4m3, both GEMMs on
-// v_mfma_f32_16x16x32_fp8_fp8.  It was correct (rel-L2 1.7-2.0e-3 against an e4m3 restatement) and bought nothing: that MFMA issues at
-// the bf16 rate, the kernel is exp-bound at head_dim 32, and attention is 9 % of the 1536^2 step - 457 vs 460 images/s.  Removed in
-// round 3 (git: 1e63651 has it); DESIGN.md "fp8" has the arithmetic.)
+// fp8 (OCP e4m3, round to nearest even) pack of 8 fp32 values, k-slot order preserved: the operand of
+// v_mfma_f32_16x16x32_fp8_fp8 holds k = 8g..8g+7 in one 64-bit register pair - the bf16 fragment layout at half the bytes.
+FVHD_DEV long pack_fp8x8(f32x8 v)
+{
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+#define ATT_VT8_STRIDE 68  // bytes per fp8 V^T row in LDS (64 keys + 4 B pad: row stride of 17 banks)
+
+// FP8 = false: Q, K, V, P are bf16 MFMA operands (the parity path, the default).
+// FP8 = true (BASELINE.json configs[4], "fp8 MFMA attention path"; opt-in: fvhd_set_attention_fp8): Q, K, V are rounded to OCP e4m3 when
+// they are staged and P = exp(s - m) in [0, 1] when it is packed, both GEMMs run on v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation;
+// the running maximum stays fp32 and the denominator sums the SAME e4m3 P values that multiply V (a ones fragment, like the bf16 form).
+// K / V tiles take half the LDS bytes.  Measured (rounds 1-2): correct, and no faster than bf16 - that MFMA issues at the bf16 rate,
+// the kernel is exp-bound at head_dim 32 and attention is 9 % of the 1536^2 step (DESIGN.md "fp8"); kept so that configs[4] runs as named.
+template <bool FP8>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                         int N, int C, float scale_log2e)
 {
@@ -114,10 +129,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     // Q fragments (B operand: n = query = lr, k = d = 8g..8g+7), ATT_QW blocks of 16 queries per wave
     int q_idx[ATT_QW];
     bf16x8 qf[ATT_QW];
+    long qf8[ATT_QW];
 #pragma unroll
     for (int w = 0; w < ATT_QW; ++w) {
         q_idx[w] = qb * ATT_QB + (wave * ATT_QW + w) * 16 + lr;
         qf[w] = *(const bf16x8*)(base + (size_t)min(q_idx[w], N - 1) * row_stride + g * 8);
+        if constexpr (FP8) qf8[w] = pack_fp8x8(bf8_to_f32(qf[w]));
     }
 
     // staging assignment: thread -> (key = tid>>2, 16-B chunk = tid&3) of the K and V tiles
@@ -125,6 +142,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     const bf16* kptr = base + C + sch * 8;
     const bf16* vptr = base + 2 * C + sch * 8;
     const int k_dst = skey * 64 + ((sch ^ ((0 - (skey >> 2)) & 3)) << 4);
+    // fp8 K tile: 32-B rows, 8-B slot s of row r at slot s ^ (2 * ((r >> 3) & 1)): the 32 lanes of one ds_read_b64 group
+    // (16 rows x 2 slots) then cover all 64 banks once
+    const int k8_dst = skey * 32 + ((sch ^ (((skey >> 3) & 1) << 1)) << 3);
 
     f32x4 o_acc[ATT_QW][2];                              // O^T[d = df*16 + 4g + r][q = lr]
     // softmax denominators on the matrix cores: a third "V^T fragment" of ones makes every row of l_acc the sum over the keys of the
@@ -133,6 +153,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     f32x4 l_acc[ATT_QW];
     float m_run[ATT_QW];
     bf16x8 ones;
+    const long ones8 = 0x3838383838383838L;              // eight e4m3 1.0
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
 #pragma unroll
@@ -155,8 +176,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     for (int t = 0; t < ntiles; ++t) {
         char* kbuf = lds + (t & 1) * (ATT_KT * 64 + ATT_D * ATT_VT_STRIDE);
         char* vbuf = kbuf + ATT_KT * 64;
-        *(u32x4*)(kbuf + k_dst) = rk;
-        {
+        if constexpr (FP8) {
+            *(long*)(kbuf + k8_dst) = pack_fp8x8(bf8_to_f32(__builtin_bit_cast(bf16x8, rk)));
+            const long v8 = pack_fp8x8(bf8_to_f32(__builtin_bit_cast(bf16x8, rv)));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(unsigned char*)(vbuf + (sch * 8 + i) * ATT_VT8_STRIDE + skey) = (unsigned char)(v8 >> (8 * i));
+        } else {
+            *(u32x4*)(kbuf + k_dst) = rk;
             const bf16x8 vv = __builtin_bit_cast(bf16x8, rv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) *(bf16*)(vbuf + (sch * 8 + i) * ATT_VT_STRIDE + skey * 2) = vv[i];
@@ -180,10 +206,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
             const int krow = kf * 16 + lr;
-            const bf16x8 kfr = *(const bf16x8*)(kbuf + krow * 64 + ((g ^ ((0 - (krow >> 2)) & 3)) << 4));
+            if constexpr (FP8) {
+                const long kfr = *(const long*)(kbuf + krow * 32 + ((g ^ (((krow >> 3) & 1) << 1)) << 3));
 #pragma unroll
-            for (int w = 0; w < ATT_QW; ++w)
-                s[w][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[w], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                for (int w = 0; w < ATT_QW; ++w)
+                    s[w][kf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kfr, qf8[w], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            } else {
+                const bf16x8 kfr = *(const bf16x8*)(kbuf + krow * 64 + ((g ^ ((0 - (krow >> 2)) & 3)) << 4));
+#pragma unroll
+                for (int w = 0; w < ATT_QW; ++w)
+                    s[w][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[w], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
         }
         if ((t + 1) * ATT_KT > N) {
             // the one tile that reaches past N (none when N % 64 == 0): a REAL wave-uniform branch - as selects inside the loop below
@@ -197,6 +230,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                     for (int r = 0; r < 4; ++r)
                         if (t * ATT_KT + kf * 16 + g * 4 + r >= N) s[w][kf][r] = -1e30f;
         }
+        long pf8[ATT_QW][2];
         bf16x8 pf[ATT_QW][2];   // B operand of O^T = V^T . P^T: n = q = lr, k-slot j <-> key (j<4 ? 4g+j : 16+4g+j-4) of chunk c
 #pragma unroll
         for (int w = 0; w < ATT_QW; ++w) {
@@ -219,7 +253,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                     p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c][r], scale_log2e, -mb));
                     p[4 + r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[w][2 * c + 1][r], scale_log2e, -mb));
                 }
-                pf[w][c] = f32_to_bf8(p);
+                if constexpr (FP8) pf8[w][c] = pack_fp8x8(p);
+                else pf[w][c] = f32_to_bf8(p);
             }
             // after the first tiles the running maximum rarely moves: alpha == 1 exactly (exp2(0)), and multiplying by it is the
             // identity - skipped when no lane of the wave saw a new maximum (same bits, 12 VALU instructions fewer per tile)
@@ -229,20 +264,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                 o_acc[w][1] *= alpha;
             }
 #pragma unroll
-            for (int c = 0; c < 2; ++c) l_acc[w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[w][c], l_acc[w], 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {
+                if constexpr (FP8) l_acc[w] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ones8, pf8[w][c], l_acc[w], 0, 0, 0);
+                else l_acc[w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[w][c], l_acc[w], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int df = 0; df < 2; ++df)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 // A operand: row = d = df*16 + lr, k-slot j <-> same key permutation as pf; one read feeds every query block
-                const char* vr = vbuf + (df * 16 + lr) * ATT_VT_STRIDE + (c * 32 + g * 4) * 2;
-                const bf16x4 lo = *(const bf16x4*)(vr);
-                const bf16x4 hi = *(const bf16x4*)(vr + 32);
-                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (FP8) {
+                    const char* vr = vbuf + (df * 16 + lr) * ATT_VT8_STRIDE + c * 32 + g * 4;
+                    const unsigned lo = *(const unsigned*)(vr), hi = *(const unsigned*)(vr + 16);
+                    const long vf = (long)(((unsigned long)hi << 32) | lo);
 #pragma unroll
-                for (int w = 0; w < ATT_QW; ++w)
-                    o_acc[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[w][c], o_acc[w][df], 0, 0, 0);
+                    for (int w = 0; w < ATT_QW; ++w)
+                        o_acc[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf, pf8[w][c], o_acc[w][df], 0, 0, 0);
+                } else {
+                    const char* vr = vbuf + (df * 16 + lr) * ATT_VT_STRIDE + (c * 32 + g * 4) * 2;
+                    const bf16x4 lo = *(const bf16x4*)(vr);
+                    const bf16x4 hi = *(const bf16x4*)(vr + 32);
+                    const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int w = 0; w < ATT_QW; ++w)
+                        o_acc[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[w][c], o_acc[w][df], 0, 0, 0);
+                }
             }
         // no second barrier: the next iteration writes the OTHER buffer, and the buffer written two
         // iterations from now is only touched after every wave has passed the next __syncthreads().
@@ -260,11 +307,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
 }
 
 // qkv [B*N, 3C] bf16 (q | k | v, head h at columns h*32) -> out [B*N, C] bf16.  C % 32 == 0.
-extern "C" int fvhd_launch_attention(hipStream_t st, const void* qkv, void* out, int B, int N, int C)
+// fp8 != 0 selects the e4m3 operand path.
+extern "C" int fvhd_launch_attention(hipStream_t st, const void* qkv, void* out, int B, int N, int C, int fp8)
 {
     if (C % ATT_D || B <= 0 || N <= 0) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(((N + ATT_QB - 1) / ATT_QB) * (C / ATT_D) * B));
     const float scale_log2e = 0.17677669529663687f * 1.4426950408889634f;   // 32^-0.5 * log2(e)
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, C, scale_log2e);
+    if (fp8) hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, C, scale_log2e);
+    else hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, C, scale_log2e);
     return (int)hipGetLastError();
 }

@@ -23,7 +23,7 @@ int fvhd_dw7_mfma_supported(int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
 int fvhd_launch_stem_fused(hipStream_t, const void*, int, void*, const float*, const float*, const float*, const float*, int, int);
-int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int);
+int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int, int);
 int fvhd_launch_stem_conv(hipStream_t, const void*, int, void*, const float*, const float*, int, int);
 int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, const float*, const float*, const float*,
                         void*, int, int, int, int, int);
@@ -147,6 +147,7 @@ struct fvhd_ctx {
     int ws_batch = 0, ws_hidden = 0;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
     bool use_fused_stem = true;  // FVHD_FUSED_STEM=0: stem[0] and stem[1] as two launches through a [B,R/2,R/2,96] HBM tensor
+    int attn_fp8 = 0;            // fvhd_set_attention_fp8 / FVHD_ATTN_FP8=1: e4m3 MFMA operands in MHSA (BASELINE.json configs[4]; opt-in)
     int batch_invariant = 0;     // fvhd_set_batch_invariant: kernel choice by image shape only (bit-identical rows in any batch)
     // fvhd_audit_ranges: while set, every ConvFFN also runs its fc1 as a plain GEMM (bias, no GELU) and reduces max |fc1 out| into
     // audit_dev[step] (fp32 bit patterns of non-negative values, ordered as unsigned integers)
@@ -155,7 +156,7 @@ struct fvhd_ctx {
     // The stem (reads the caller's images) and the head (writes the caller's buffer) stay outside the graph, so a cached
     // graph only holds library-owned pointers (workspace, packed weights) and is valid for any caller buffers.
     struct GraphEntry {
-        int B, fused;              // fused: bit 0 fused ConvFFN, bit 1 batch-invariant dispatch
+        int B, fused;              // fused: bit 0 fused ConvFFN, bit 1 batch-invariant dispatch, bit 2 e4m3 attention operands
         char* ws;
         hipGraphExec_t exec;       // nullptr until the second call with this key (the first runs eagerly), or when capture failed
         bool failed;
@@ -493,7 +494,7 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
         if ((e = run_gemm(c, st, C_QKV, c->wdev, blk.qkv, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_NONE))) return e;
         {
             Scope s(c, st, C_ATT);
-            CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C), "attention launch");
+            CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C, c->attn_fp8), "attention launch");
         }
         if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID))) return e;
         return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, (int)(&sp - c->m.steps.data()));
@@ -554,7 +555,7 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
 
     // ---- stem | graph of the interior steps | head ----
     if ((e = run_step(c, st, c->m.steps[0], w, X, T, B, images, img_dtype, nullptr, 0))) return e;
-    const int fkey = (int)c->use_fused_ffn | (c->batch_invariant << 1);
+    const int fkey = (int)c->use_fused_ffn | (c->batch_invariant << 1) | (c->attn_fp8 << 2);
     fvhd_ctx::GraphEntry* g = nullptr;
     for (auto& q : c->graphs)
         if (q.B == B && q.fused == fkey && q.ws == c->ws) g = &q;
@@ -635,6 +636,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_FUSED_STEM")) c->use_fused_stem = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_GRAPH")) c->graph = atoi(ev) != 0;
     *out = c;
     return 0;
@@ -871,6 +873,13 @@ int fvhd_set_graph(fvhd_ctx* c, int on)
     return 0;
 }
 
+int fvhd_set_attention_fp8(fvhd_ctx* c, int on)
+{
+    if (!c) return fail("fvhd_set_attention_fp8: ctx is NULL");
+    c->attn_fp8 = on != 0;       // (cached graphs are keyed by it)
+    return 0;
+}
+
 int fvhd_set_batch_invariant(fvhd_ctx* c, int on)
 {
     if (!c) return fail("fvhd_set_batch_invariant: ctx is NULL");
@@ -1027,8 +1036,14 @@ int fvhd_op_layernorm(fvhd_stream_t st, const void* x, void* y, const float* w, 
 
 int fvhd_op_attention(fvhd_stream_t st, const void* qkv, void* out, int B, int N, int C)
 {
-    int e = fvhd_launch_attention((hipStream_t)st, qkv, out, B, N, C);
+    int e = fvhd_launch_attention((hipStream_t)st, qkv, out, B, N, C, 0);
     return e ? hip_fail("fvhd_op_attention", (hipError_t)e) : 0;
+}
+
+int fvhd_op_attention_fp8(fvhd_stream_t st, const void* qkv, void* out, int B, int N, int C)
+{
+    int e = fvhd_launch_attention((hipStream_t)st, qkv, out, B, N, C, 1);
+    return e ? hip_fail("fvhd_op_attention_fp8", (hipError_t)e) : 0;
 }
 
 int fvhd_op_stem_conv(fvhd_stream_t st, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R)

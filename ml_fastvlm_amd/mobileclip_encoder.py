@@ -104,6 +104,10 @@ class MobileCLIPVisionTower(nn.Module):
         # MI355X-only options (no counterpart in the reference), read from the config object like the reference reads its own
         # switches.  Tri-state: None = leave the library's setting alone (fvhd_create reads FVHD_GRAPH from the environment,
         # INTEGRATION.md); True / False = explicit, pushed to the context before every call.
+        # e4m3 MFMA operands in the MHSA core: the "fp8 MFMA attention path" BASELINE.json configs[4] names (include/fvhd.h:
+        # fvhd_set_attention_fp8); opt-in, measured no faster than the bf16 parity path (DESIGN.md "fp8")
+        fp8 = getattr(args, "mm_vision_attention_fp8", None)
+        self.attention_fp8 = None if fp8 is None else bool(fp8)
         # hipGraph replay of the tower's interior launches (include/fvhd.h: fvhd_set_graph), for launch-bound batches
         graph = getattr(args, "mm_vision_hip_graph", None)
         self.hip_graph = None if graph is None else bool(graph)
@@ -188,6 +192,8 @@ class MobileCLIPVisionTower(nn.Module):
             self._ctx.finalize()
             self._dirty = False
             self._apply_ffn_precision(self._ctx)
+        if self.attention_fp8 is not None:
+            self._ctx.set_attention_fp8(self.attention_fp8)
         if self.hip_graph is not None:
             self._ctx.set_graph(self.hip_graph)
         if self.batch_invariant is not None:

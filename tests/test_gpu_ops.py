@@ -422,6 +422,53 @@ def test_attention_forced_rescale():
     _close(out, _attention_ref(qkv, B, N, C), rtol=2e-2, atol_rms=2e-2, what="attention spike")
 
 
+def _f8(x):
+    return x.to(torch.float8_e4m3fn).float()
+
+
+def _attention_ref_fp8(qkv, B, N, C, tile=64):
+    """The fp8 kernel's arithmetic restated: Q, K, V rounded to OCP e4m3; per 64-key tile the online softmax with an fp32 running
+    maximum, P = exp(s - running max) rounded to e4m3 before the PV product AND before the row sum (the denominator is accumulated on
+    the matrix cores from the same e4m3 P values that multiply V)."""
+    nh = C // 32
+    t = qkv.float().reshape(B, N, 3, nh, 32).permute(2, 0, 3, 1, 4)
+    q, k, v = (_f8(x) for x in t.unbind(0))
+    scale = 32 ** -0.5
+    m = torch.full((B, nh, N, 1), -1e30)
+    l = torch.zeros(B, nh, N, 1)
+    o = torch.zeros(B, nh, N, 32)
+    for k0 in range(0, N, tile):
+        s = q @ k[:, :, k0:k0 + tile].transpose(-2, -1)
+        m_new = torch.maximum(m, s.amax(-1, keepdim=True))
+        alpha = torch.exp((m - m_new) * scale)
+        pr = _f8(torch.exp((s - m_new) * scale))
+        l = l * alpha + pr.sum(-1, keepdim=True)
+        o = o * alpha + pr @ v[:, :, k0:k0 + tile]
+        m = m_new
+    return (o / l).transpose(1, 2).reshape(B * N, C)
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 16, 64), (2, 100, 96), (1, 256, 1536), (1, 1024, 64), (1, 2304, 64), (1, 576, 64)])
+def test_attention_fp8(B, N, C):
+    """BASELINE.json configs[4] "fp8 MFMA attention path" (opt-in).  STATED TOLERANCE: rel-L2 <= 1e-2 against the e4m3 restatement
+    (bf16 output rounding + accumulation order + rare e4m3 rounding flips of P), and the distance to the exact softmax attention
+    <= 1e-1 (e4m3 has 3 mantissa bits: 6 % per operand, averaged over 32 channels and N keys)."""
+    lib = _lib.load()
+    qkv = _bf(_rand(B * N, 3 * C, seed=1, scale=1.5))
+    out = torch.empty(B * N, C, dtype=torch.bfloat16, device=DEV)
+    qd = qkv.to(DEV)
+    _lib.check(lib.fvhd_op_attention_fp8(_stream(), _p(qd), _p(out), B, N, C), "attention fp8")
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    emu, exact = _attention_ref_fp8(qkv, B, N, C), _attention_ref(qkv, B, N, C)
+    rel_emu = ((got - emu).norm() / emu.norm()).item()
+    rel_exact = ((got - exact).norm() / exact.norm()).item()
+    print(f"attention fp8 B{B} N{N} C{C}: rel-L2 vs e4m3 restatement {rel_emu:.3e}, vs exact attention {rel_exact:.3e}")
+    assert torch.isfinite(got).all()
+    assert rel_emu <= 1e-2, rel_emu
+    assert rel_exact <= 1e-1, rel_exact
+
+
 # ------------------------------------------------------------------------------------------- stem / head
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_stem_conv(dtype):

@@ -53,7 +53,9 @@ def test_mi355x_options_default_off_and_read_from_args():
     t = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_batch_invariant=True,
                                                                     mm_vision_hip_graph=1), delay_load=True)
     assert t.batch_invariant is True and t.hip_graph is True
-    assert not hasattr(t, "attention_fp8")                      # the e4m3 attention option of rounds 1-2 is gone (DESIGN.md "fp8")
+    assert t.attention_fp8 is None                              # the e4m3 attention operands of BASELINE configs[4] are opt-in
+    t = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_attention_fp8=True), delay_load=True)
+    assert t.attention_fp8 is True
 
 
 def test_unknown_names_raise_value_error():

@@ -8,7 +8,7 @@
 set -u
 TAG=${1:-r02}
 export TMPDIR=/tmp
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-ttft"
 mkdir -p gpurun_out
 run() { # name, extra rocprofv3 args...
     local name=$1; shift
