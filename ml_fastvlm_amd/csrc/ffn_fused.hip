@@ -106,6 +106,9 @@ template <int H> FVHD_DEV void gelu_half(GeluSt& g, f32x2 x, f32x2& out)
 // erf GELU (tools/ubench/g16.py): relative 0.5-1.0e-3, against 1.7e-3 for f32 math + rounding to bf16 - P now carries 11 mantissa bits
 // instead of 8; |Phi error| <= 1.4e-3; Phi = 1 exactly from x = 3.5 on and 0 exactly below -3.51 (c0 is nudged one ulp up for that; at -3.5
 // itself the half-precision sum leaves 2^-13 against the true 2.3e-4) - tests/test_gelu_f16.py restates the sequence in numpy.
+#ifndef FVHD_FFN_DMARUN
+#define FVHD_FFN_DMARUN 1            // weight DMA as runs of consecutive pieces (0: one statement per piece, the round 1-3 form)
+#endif
 #ifndef FVHD_FFN_F16
 #define FVHD_FFN_F16 2               // 2: every C;  1: C <= 192 only;  0: the f32 GELU + bf16 GEMM2 of rounds 1-2   (A/B builds: -DFVHD_FFN_F16=0)
 #endif
@@ -213,8 +216,24 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
         }
         if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);  // the MFMA opens the slot; everything below issues in its shadow
         if (nb == 0 && f + PF < NF && FFN_LD_ON(f + PF)) wf[f + PF] = FFN_LD(f + PF);
-        if constexpr (DO_DMA) {             // next iteration's weight images, one 1-KiB piece per DSTRIDE slots
-            if (m % DSTRIDE == 0 && m / DSTRIDE < NPW) {
+        if constexpr (DO_DMA) {             // next iteration's weight images
+#if FVHD_FFN_DMARUN
+            // RUNS of 3-4 consecutive 1-KiB pieces per statement (glds16_run: one M0 setting, scalar base + the constant lane offset,
+            // the instruction offset advances the global and the LDS side together): 2-3 issue slots per piece instead of 7 (M0 save /
+            // set / nop / restore + a 64-bit VALU address per piece) - the iteration is issue-bound (~6 instructions per MFMA gap
+            // against the ~5 one wave per SIMD hides), and the per-piece form spent 84 of its ~300 instructions at C = 384 on this.
+            // Waves 0-1 stream W1, waves 2-3 W2; a wave's PPW pieces are consecutive in the (linear) chunk image.
+            constexpr int PPW = TP / DW, RUN = PPW % 4 == 0 ? 4 : 3, NRUN = PPW / RUN, RSTRIDE = (NM / 2) / NRUN > 0 ? (NM / 2) / NRUN : 1;
+            static_assert(PPW % RUN == 0 && DW == 4 && NG % PPW == 0, "a wave's pieces lie in one matrix");
+            if (m % RSTRIDE == 0 && m / RSTRIDE < NRUN) {
+                const int second = uwave >> 1;                                            // wave-uniform (SGPR)
+                const unsigned pc0 = (unsigned)((uwave & 1) * PPW + (m / RSTRIDE) * RUN) * 1024u;
+                const char* sb = (second ? dma_src2 : dma_src1) + pc0;
+                const unsigned dst = (second ? dma_dst2 : dma_dst1) + pc0;
+                if (second ? dma2 : dma1) glds16_run<RUN>(sb, (threadIdx.x & 63) * 16u, dst);
+            }
+#else
+            if (m % DSTRIDE == 0 && m / DSTRIDE < NPW) {    // one 1-KiB piece per DSTRIDE slots
                 const int flat = (m / DSTRIDE) * DW + uwave;
                 const int lane16 = (threadIdx.x & 63) * 16;
                 const bool second = flat >= NG;
@@ -223,6 +242,7 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
                 const unsigned dst = (second ? dma_dst2 : dma_dst1) + (unsigned)pc * 1024u;
                 if (second ? dma2 : dma1) glds16(src, dst);              // compile-time or loop-invariant flags only
             }
+#endif
         }
         if constexpr (DO_B) {               // GELU; value r of block gb <-> hidden h = (r&3) + 8(r>>2) + 4*half
             if constexpr (!BPRE) {
@@ -345,24 +365,30 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     // 128-B line per request).  For C <= 192 the tile is read fully coalesced (lane L of load i takes 16-B chunk i*64+L)
     // and transposed through LDS - the (still empty) weight rings - with a 16-B-slot XOR swizzle that keeps both sides
     // conflict-free.
-    static_assert(NB == 1 && WAVES == 4, "the LDS transpose uses one quarter of the 4*CHB ring area per wave");
+    static_assert((NB == 1 || NB == 2) && WAVES == 4, "the LDS transpose uses one quarter of the 4*CHB ring area per wave, one 32-row block at a time");
     constexpr int CPR = C / 8;               // 16-B chunks per row
     constexpr int NL = 32 * CPR / 64;        // coalesced 16-B loads per lane for one 32-row tile (== KS)
     char* stage = smem + wave * (32 * C * 2);
     const size_t tile_b = (size_t)row0 * C * 2, last_b = (size_t)M * C * 2 - 16;     // rows >= M: any valid address (never stored)
     constexpr bool CIO = C <= 192;           // C = 384: measured slower (register spills in the edges, serialised W1[0] DMA)
+    constexpr size_t BLK_B = (size_t)32 * C * 2;      // bytes of one 32-row block (contiguous in HBM)
     if constexpr (CIO) {
-        u32x4 t[NL];
+        u32x4 t[NB][NL];
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const size_t gb = tile_b + (size_t)(i * 64 + lane) * 16;
-            t[i] = *(const u32x4*)((const char*)A + (gb < last_b ? gb : last_b));
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const size_t gb = tile_b + nb * BLK_B + (size_t)(i * 64 + lane) * 16;
+                t[nb][i] = *(const u32x4*)((const char*)A + (gb < last_b ? gb : last_b));
+            }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {       // the blocks of a wave go through its staging area one after the other
+#pragma unroll
+            for (int i = 0; i < NL; ++i) *(u32x4*)(stage + ffn_slot_of<C>(i * 64 + lane)) = t[nb][i];
+            // same wave wrote and reads: LDS operations of one wave are processed in order, no barrier needed
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) afr[nb][ks] = *(const bf16x8*)(stage + ffn_slot_of<C>(li * CPR + ks * 2 + half));
         }
-#pragma unroll
-        for (int i = 0; i < NL; ++i) *(u32x4*)(stage + ffn_slot_of<C>(i * 64 + lane)) = t[i];
-        // same wave wrote and reads: LDS operations of one wave are processed in order, no barrier needed
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) afr[0][ks] = *(const bf16x8*)(stage + ffn_slot_of<C>(li * CPR + ks * 2 + half));
     } else {
         // straight from global: lane reads 16 B of its own row per k-step
 #pragma unroll
@@ -413,30 +439,34 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     }
     // the residual tile of X is fetched now, coalesced like A^T above (the A^T registers are dead from here on), so that
     // its HBM latency hides behind the last two pipeline iterations instead of stalling the epilogue
-    u32x4 xq[CIO ? NL : 1];
+    u32x4 xq[CIO ? NB : 1][CIO ? NL : 1];
     bf16x4 xres[NB][NFR][4];
-    if constexpr (CIO) {
-        int xln = lane;
-        asm volatile("" : "+v"(xln));
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const size_t gb = tile_b + (size_t)(i * 64 + xln) * 16;
-            xq[i] = *(const u32x4*)((const char*)X + (gb < last_b ? gb : last_b));
-        }
-    } else {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const bf16* xrd = X + (size_t)min(row0 + nb * 32 + li, M - 1) * C + 4 * half;
-#pragma unroll
-        for (int nf = 0; nf < NFR; ++nf)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xres[nb][nf][q] = *(const bf16x4*)(xrd + nf * 32 + 8 * q);
+    // (C = 96 with two blocks per wave: the 48 registers of the prefetched X tile would not fit beside the pipeline's live state under
+    // the 256-register limit of two waves per SIMD - there the tile is fetched after the last iteration instead)
+    constexpr bool XPRE = !(C == 96 && NB == 2);
+#define FFN_LOAD_X()                                                                                                   \
+    if constexpr (CIO) {                                                                                               \
+        int xln = lane;                                                                                                \
+        asm volatile("" : "+v"(xln));                                                                                  \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                              \
+            _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                                           \
+                const size_t gb = tile_b + nb * BLK_B + (size_t)(i * 64 + xln) * 16;                                   \
+                xq[nb][i] = *(const u32x4*)((const char*)X + (gb < last_b ? gb : last_b));                             \
+            }                                                                                                          \
+    } else {                                                                                                           \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                            \
+            const bf16* xrd = X + (size_t)min(row0 + nb * 32 + li, M - 1) * C + 4 * half;                              \
+            _Pragma("unroll") for (int nf = 0; nf < NFR; ++nf)                                                         \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) xres[nb][nf][q] = *(const bf16x4*)(xrd + nf * 32 + 8 * q); \
+        }                                                                                                              \
     }
-    }
+    if constexpr (XPRE) { FFN_LOAD_X() }
     FFN_SYNC();                      // t = NCH (even): GELU(S(NCH-1) in s1) -> p1, GEMM2(chunk NCH-2) reads p0; DMA W2[NCH-1]
     ffn_iter<C, NB, WAVES, false, true, true, !(VAR & 1), VAR, PF, F16>(afr, o, s0, s1, p1, p0, w1p, w2p, 0, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
     FFN_SYNC();                      // t = NCH + 1: GEMM2(chunk NCH-1) reads p1
     ffn_iter<C, NB, WAVES, false, false, true, false, VAR, PF, F16>(afr, o, s1, s0, p0, p1, w1p, w2p, 1, lb1, FFN_B1PREV(lb1), half, FFN_DMA_ARGS(NCH));
+    if constexpr (!XPRE) { FFN_LOAD_X() }
+#undef FFN_LOAD_X
 #undef FFN_DMA_ARGS
 
     // ---- epilogue.  The accumulators are in MFMA layout (lane = row li, 4 consecutive channels n0 = nf*32 + 8q + 4*half per
@@ -451,7 +481,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     asm volatile("" : "+v"(eln));
     const int eli = eln & 31, ehalf = eln >> 5;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) *(u32x4*)(stage + ffn_slot_of<C>(i * 64 + eln)) = xq[i];
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *(u32x4*)(stage + ffn_slot_of<C>(i * 64 + eln)) = xq[nb][i];
 #pragma unroll
     for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
@@ -462,15 +494,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
             const f32x4 rv = bf4_to_f32(*(const bf16x4*)slot);
             f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = rv[j] + lv[j] * (o[0][nf][4 * q + j] + bv[j]);
+            for (int j = 0; j < 4; ++j) v[j] = rv[j] + lv[j] * (o[nb][nf][4 * q + j] + bv[j]);
             *(bf16x4*)slot = f32_to_bf4(v);
         }
-    const int rows_ok = M - row0;            // rows of this tile that exist
+    const int rows_ok = M - row0 - nb * 32;  // rows of this block that exist
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int id = i * 64 + eln;
         const u32x4 v = *(const u32x4*)(stage + ffn_slot_of<C>(id));
-        if (id < rows_ok * CPR) *(u32x4*)((char*)X + tile_b + (size_t)id * 16) = v;
+        if (id < rows_ok * CPR) *(u32x4*)((char*)X + tile_b + nb * BLK_B + (size_t)id * 16) = v;
+    }
     }
     } else {
     // ---- epilogue: lane holds out[m][n0 .. n0+3], n0 = nf*32 + 8q + 4*half -------------------------
@@ -628,7 +661,18 @@ extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* 
         return (int)e;
     }
     if (precision != 0) return (int)e;
+#ifndef FVHD_FFN_OCC96
+#define FVHD_FFN_OCC96 2
+#endif
+#ifndef FVHD_FFN_NB192
+#define FVHD_FFN_NB192 1             // 32-row blocks per wave at C = 192 (2: 64 rows per wave, 256 per workgroup, one wave per SIMD)
+#endif
+#ifndef FVHD_FFN_NB96
+#define FVHD_FFN_NB96 1
+#endif
     if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
+    else if (C == 192 && FVHD_FFN_NB192 == 2) e = launch_ffn<192, 2, 4, 0, 3, 1>(st, a, w1, w2, b1, b2, ls, x, M);
+    else if (C == 96 && FVHD_FFN_NB96 == 2) e = launch_ffn<96, 2, 4, 0, 3, FVHD_FFN_OCC96>(st, a, w1, w2, b1, b2, ls, x, M);
     else if (C == 192) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
     // C = 96: 152 registers since the epilogue offsets stopped being hoisted -> three workgroups (waves) per SIMD: the kernel is
     // VALU-issue-bound (16 GELUs per 12 MFMAs), a third instruction stream per SIMD is what it needs

@@ -1,0 +1,37 @@
+#!/bin/bash
+# The round's GPU calls, ONE script with stages (run ON the GPU box through gpurun, from the repo root):
+#     gpurun --timeout 1500 -- 'bash tools/gpu_run.sh <stage> [tag]'
+# Everything lands under gpurun_out/<tag>_*; summaries worth keeping are copied into profiles/ by hand afterwards.
+set -u
+STAGE=${1:-suite}
+TAG=${2:-r04}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out/${TAG}
+case "$STAGE" in
+suite)      # the whole GPU suite + the driver's bench line
+    timeout 1200 python -m pytest tests -m gpu -x -q --durations=12 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log
+    timeout 600 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cut -c1-600 ${O}_bench.json
+    ;;
+ffn)        # fused ConvFFN variants: correctness of the variant library, sustained time / power / energy per launch, whole step
+    for lib in "" nb2; do
+        L=ml_fastvlm_amd/libfvhd${lib:+_$lib}.so
+        [ -f $L ] || { echo "missing $L"; continue; }
+        [ -n "$lib" ] && FVHD_LIB=$L timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "ffn" > ${O}_ffn_${lib}_pytest.log 2>&1 && tail -1 ${O}_ffn_${lib}_pytest.log
+        FVHD_LIB=$L timeout 300 python tools/power_probe.py ffn384 ffn192 ffn96 2>/dev/null | tee -a ${O}_ffn_power.log
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_${lib:-base}.json 2>/dev/null; python - <<PY
+import json
+d=json.load(open("${O}_bench_${lib:-base}.json")); print("${lib:-base}", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items()})
+PY
+    done
+    ;;
+extra)      # the other BASELINE configs: TTFT at the 7B width, 1536^2 with bf16 / e4m3 attention operands
+    timeout 600 python bench.py --ttft --hidden 3584 --steps 10 --warmup 2 > ${O}_ttft_h3584.json 2> ${O}_ttft_h3584.err; echo "ttft3584 rc=$?"; cut -c1-400 ${O}_ttft_h3584.json
+    timeout 400 python bench.py --res 1536 --batch 16 --no-cpu-baseline --no-ttft > ${O}_bench_1536.json 2>/dev/null; echo "1536 rc=$?"; cut -c1-300 ${O}_bench_1536.json
+    timeout 400 python bench.py --res 1536 --batch 16 --attn-fp8 --no-cpu-baseline --no-ttft > ${O}_bench_1536_fp8.json 2>/dev/null; echo "1536 fp8 rc=$?"; cut -c1-300 ${O}_bench_1536_fp8.json
+    ;;
+pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
+    bash tools/run_pmc.sh ${TAG}
+    ;;
+*)  echo "unknown stage $STAGE"; exit 2;;
+esac

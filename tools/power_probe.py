@@ -173,7 +173,9 @@ def run(name, seconds=3.0):
         cap = int(open(s.capfile).read()) / 1e6 if s.capfile else None
     except Exception:
         pass
-    print(f"{name:8s} variant {os.environ.get('FVHD_FFN_VARIANT', '0')}: {1e6 * dt / max(n, 1):8.1f} us/launch  {flops * n / dt / 1e12:7.1f} TF/s | power mean {sum(pw) / len(pw):6.0f} W max {max(pw):6.0f} W"
+    us = 1e6 * dt / max(n, 1)
+    print(f"{name:8s} lib {os.path.basename(_lib.LIB_PATH)} variant {os.environ.get('FVHD_FFN_VARIANT', '0')} prec {FFN_PREC}: {us:8.1f} us/launch  {flops * n / dt / 1e12:7.1f} TF/s | "
+          f"energy {sum(pw) / len(pw) * us * 1e-3:7.1f} mJ/launch | power mean {sum(pw) / len(pw):6.0f} W max {max(pw):6.0f} W"
           f" (cap {cap}) | sclk mean {sum(clk) / len(clk):5.0f} MHz | {len(pw)} samples via {'sysfs' if s.pfile else 'rocm-smi'}")
 
 
