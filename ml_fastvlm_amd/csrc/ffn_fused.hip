@@ -106,6 +106,12 @@ template <int H> FVHD_DEV void gelu_half(GeluSt& g, f32x2 x, f32x2& out)
 // erf GELU (tools/ubench/g16.py): relative 0.5-1.0e-3, against 1.7e-3 for f32 math + rounding to bf16 - P now carries 11 mantissa bits
 // instead of 8; |Phi error| <= 1.4e-3; Phi = 1 exactly from x = 3.5 on and 0 exactly below -3.51 (c0 is nudged one ulp up for that; at -3.5
 // itself the half-precision sum leaves 2^-13 against the true 2.3e-4) - tests/test_gelu_f16.py restates the sequence in numpy.
+#ifndef FVHD_FFN_CIO384
+#define FVHD_FFN_CIO384 1            // C = 384: A / X tiles read and written as whole lines through an LDS transpose, like C <= 192 (0: 16-B / 8-B row accesses)
+#endif
+#ifndef FVHD_FFN_PAIRWAIT
+#define FVHD_FFN_PAIRWAIT 1          // fragment reads in pairs behind one explicit s_waitcnt (0: one read and one compiler-placed wait per MFMA)
+#endif
 #ifndef FVHD_FFN_DMARUN
 #define FVHD_FFN_DMARUN 1            // weight DMA as runs of consecutive pieces (0: one statement per piece, the round 1-3 form)
 #endif
@@ -133,6 +139,30 @@ template <int H> FVHD_DEV void gelu_half16(GeluSt16& g, f32x2 x, f16x2& out)
         f16x2 phi;
         asm("v_pk_fma_f16 %0, %1, %2, %3 clamp" : "=v"(phi) : "v"(g.x), "v"(g.q), "v"(FFN_H2(0x3800)));
         out = g.x * phi;
+    }
+}
+
+// The same ten packed instructions, ONE per call (round 4): the iteration issues stage k of several INDEPENDENT pairs in a slot and
+// stage k + 1 in the next, so that no packed instruction directly follows the one it depends on - hipcc separated every such pair
+// with an s_nop (66 of the 833 instructions of two iterations at C = 384), and the iteration is issue-bound.
+template <int K> FVHD_DEV void gelu16_stage(GeluSt16& g, f32x2 x, f16x2& out)
+{
+    if constexpr (K == 0) g.x = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+    else if constexpr (K == 1) g.u = g.x * g.x;
+    else if constexpr (K == 2) g.u = __builtin_elementwise_min(g.u, FFN_H2(0x3a20));          // (3.5 / 4)^2 = 0.765625
+    else if constexpr (K == 3) g.q = __builtin_elementwise_fma(FFN_H2(0xc1b0), g.u, FFN_H2(0x4878));
+    else if constexpr (K == 4) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0xc9e5));
+    else if constexpr (K == 5) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0x485a));
+    else if constexpr (K == 6) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0xc41f));
+    else if constexpr (K == 7) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0x3e5f));
+    else if constexpr (K == 8) asm("v_pk_fma_f16 %0, %1, %2, %3 clamp" : "=v"(g.q) : "v"(g.x), "v"(g.q), "v"(FFN_H2(0x3800)));
+    else out = g.x * g.q;
+}
+template <int K = 0> FVHD_DEV void gelu16_dispatch(int k, GeluSt16& g, f32x2 x, f16x2& out)
+{
+    if constexpr (K < 10) {
+        if (k == K) gelu16_stage<K>(g, x, out);
+        else gelu16_dispatch<K + 1>(k, g, x, out);
     }
 }
 
@@ -187,13 +217,27 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
         for (int q = 0; q < 4; ++q) bv[q] = *(const f32x4*)(b1_cur + 8 * q + 4 * half);
     }
     if constexpr (DO_B && !BPRE) bv[0] = *(const f32x4*)(b1_prev + 4 * half);
+    // PAIRW (round 4, steady-state iterations of the half-precision form with one block per wave): fragments are fetched in PAIRS -
+    // slot 2j issues the reads of fragments 2j + 4 and 2j + 5, slot 2j + 1 none - behind ONE explicit s_waitcnt per pair
+    // (lgkmcnt(2): everything but the pair read last has landed, i.e. fragments 2j and 2j + 1); hipcc's own insertion then finds the
+    // second MFMA's operand already covered and adds nothing: 24 instead of 49 s_waitcnt per iteration at C = 384, each of which
+    // took an issue slot of the issue-bound loop.  (A count that is too permissive would only make hipcc add its own wait back.)
+    constexpr bool PAIRW = FVHD_FFN_PAIRWAIT && PIN && F16 && BPRE && NB == 1 && DO_A && DO_B && DO_C && !(VAR & (4 | 8));
+    constexpr int PFE = PAIRW ? 4 : PF;         // fragments in flight ahead of the MFMA stream
 #pragma unroll
-    for (int f = 0; f < PF; ++f)
+    for (int f = 0; f < PFE; ++f)
         if (FFN_LD_ON(f)) wf[f] = FFN_LD(f);
     if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         const int f = m / NB, nb = m % NB;
+        if constexpr (PAIRW) {
+            if ((f & 1) == 0) {
+                // fragment reads issued after f + 1: {f + 2, f + 3} while they exist
+                if (f + 2 < NF) __builtin_amdgcn_s_waitcnt(0xc27f);     // lgkmcnt(2)
+                else __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+            }
+        }
         if ((f & 1) == 0) {
             if constexpr (DO_A) {
                 const int ks = f >> 1;
@@ -215,7 +259,12 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
             }
         }
         if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);  // the MFMA opens the slot; everything below issues in its shadow
-        if (nb == 0 && f + PF < NF && FFN_LD_ON(f + PF)) wf[f + PF] = FFN_LD(f + PF);
+        if constexpr (PAIRW) {
+            if ((f & 1) == 0) {
+                if (f + 4 < NF) wf[f + 4] = FFN_LD(f + 4);
+                if (f + 5 < NF) wf[f + 5] = FFN_LD(f + 5);
+            }
+        } else if (nb == 0 && f + PF < NF && FFN_LD_ON(f + PF)) wf[f + PF] = FFN_LD(f + PF);
         if constexpr (DO_DMA) {             // next iteration's weight images
 #if FVHD_FFN_DMARUN
             // RUNS of 3-4 consecutive 1-KiB pieces per statement (glds16_run: one M0 setting, scalar base + the constant lane offset,
@@ -223,11 +272,12 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
             // set / nop / restore + a 64-bit VALU address per piece) - the iteration is issue-bound (~6 instructions per MFMA gap
             // against the ~5 one wave per SIMD hides), and the per-piece form spent 84 of its ~300 instructions at C = 384 on this.
             // Waves 0-1 stream W1, waves 2-3 W2; a wave's PPW pieces are consecutive in the (linear) chunk image.
-            constexpr int PPW = TP / DW, RUN = PPW % 4 == 0 ? 4 : 3, NRUN = PPW / RUN, RSTRIDE = (NM / 2) / NRUN > 0 ? (NM / 2) / NRUN : 1;
-            static_assert(PPW % RUN == 0 && DW == 4 && NG % PPW == 0, "a wave's pieces lie in one matrix");
+            // (DW waves: the first DW / 2 stream W1, the others W2)
+            constexpr int PPW = TP / DW, RUN = PPW % 4 == 0 ? 4 : PPW % 3 == 0 ? 3 : PPW, NRUN = PPW / RUN, RSTRIDE = (NM / 2) / NRUN > 0 ? (NM / 2) / NRUN : 1;
+            static_assert(TP % DW == 0 && PPW % RUN == 0 && RUN <= 4 && DW % 2 == 0 && NG % PPW == 0, "a wave's pieces lie in one matrix");
             if (m % RSTRIDE == 0 && m / RSTRIDE < NRUN) {
-                const int second = uwave >> 1;                                            // wave-uniform (SGPR)
-                const unsigned pc0 = (unsigned)((uwave & 1) * PPW + (m / RSTRIDE) * RUN) * 1024u;
+                const int second = uwave >= DW / 2;                                       // wave-uniform (SGPR)
+                const unsigned pc0 = (unsigned)((uwave % (DW / 2)) * PPW + (m / RSTRIDE) * RUN) * 1024u;
                 const char* sb = (second ? dma_src2 : dma_src1) + pc0;
                 const unsigned dst = (second ? dma_dst2 : dma_dst1) + pc0;
                 if (second ? dma2 : dma1) glds16_run<RUN>(sb, (threadIdx.x & 63) * 16u, dst);
@@ -250,6 +300,27 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
                 for (int q = 1; q < 4; ++q)     // bias of values 4q..4q+3 (first used by unit 24*q*NB): read ~2 slots ahead
                     if (m == ((24 * q * NB) / UPS >= 2 ? (24 * q * NB) / UPS - 2 : 0)) bv[q] = *(const f32x4*)(b1_prev + 8 * q + 4 * half);
             }
+            if constexpr (F16 && !(VAR & (2 | 64))) {
+                // half-precision form: slot m issues stage k = m % 10 of the UPS pairs of group m / 10 (NM / 12 groups of UPS = 48 / KS
+                // pairs: 8 NB pairs per iteration) - one instruction per pair and slot, all of them independent of each other
+                constexpr int NGRP = NM / 12;
+                static_assert(NGRP * UPS == 8 * NB && NGRP * 10 <= NM, "ten stages of every pair group fit into the iteration's slots");
+                if (m / 10 < NGRP) {
+                    const int k = m % 10;
+#pragma unroll
+                    for (int i = 0; i < UPS; ++i) {
+                        const int pr = (m / 10) * UPS + i, gb = pr % NB, r = 2 * (pr / NB);      // pair (values r, r + 1) of block gb
+                        const f32x2 sv = {s_in[gb][r], s_in[gb][r + 1]};
+                        gelu16_dispatch(k, gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                        if (k == 9) {
+                            f16x8 pt = __builtin_bit_cast(f16x8, p_out[gb][r >> 3]);
+                            pt[r & 7] = gout16[gb][r >> 1][0];
+                            pt[(r & 7) + 1] = gout16[gb][r >> 1][1];
+                            p_out[gb][r >> 3] = __builtin_bit_cast(bf16x8, pt);
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int u = m * UPS / 2; u < (m + 1) * UPS / 2; ++u) {     // unit u = ((pair j, half-stage h), block gb)
                 // f32 form: one pair at a time (register budget at C = 384); f16 form: two pairs in flight with their half-stages
@@ -336,7 +407,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     // [W1 ring: 2 x CHB][W2 ring: 2 x CHB][b1 fp32 HID]   - one array: see cdna_hip_programming.md 5 item 4(a)
     char* w1ring = smem;
     char* w2ring = smem + 2 * CHB;
-    float* lb1 = (float*)(smem + 4 * CHB);
+    // C = 384 with the coalesced tile I/O (FVHD_FFN_CIO384): the transposing stage of the tile prologue must not sit in the W1 ring
+    // (W1[0] is streamed in while the A tile is staged), so it starts at the W2 ring and runs 4 * 24 KB = 96 KB from there, past the
+    // 4 * CHB of the rings; b1 moves behind it.  C <= 192: the stage is the (still empty) ring area itself.
+    constexpr bool CIO = C <= 192 || FVHD_FFN_CIO384;
+    constexpr int STAGE0 = (C == 384 && CIO) ? 2 * CHB : 0;
+    constexpr int STAGE_END = CIO ? STAGE0 + WAVES * (32 * C * 2) : 0;     // (more than 4 waves at C <= 192: the stage outgrows the rings)
+    float* lb1 = (float*)(smem + (STAGE_END > 4 * CHB ? STAGE_END : 4 * CHB));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
@@ -356,6 +433,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 #pragma unroll
     for (int k = 0; k < 2; ++k) w2p[k] = w2ring + w2_off(li, 2 * k + half);
 
+#define FFN_W1_FIRST()                                                                                                  \
+    _Pragma("unroll") for (int g = 0; g < (NG + WAVES - 1) / WAVES; ++g) {             /* W1[0] */                      \
+        const int piece = g * WAVES + uwave;                                                                           \
+        if (NG % WAVES == 0 || piece < NG) glds16(w1img + piece * 1024 + lane * 16, lds_w1 + piece * 1024);            \
+    }
+    // (STAGE0 != 0: the stage does not overlap the W1 ring - W1[0] streams in while the A tile is staged; the W2 ring, which the stage
+    // does overlap, is first written during iteration 1, two barriers after the last fragment read)
+    if constexpr (CIO && STAGE0 != 0) { FFN_W1_FIRST() }
     bf16x8 afr[NB][KS];
     f32x16 o[NB][NFR];
     f32x16 s0[NB], s1[NB];          // s[k&1] holds S(k)
@@ -365,12 +450,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
     // 128-B line per request).  For C <= 192 the tile is read fully coalesced (lane L of load i takes 16-B chunk i*64+L)
     // and transposed through LDS - the (still empty) weight rings - with a 16-B-slot XOR swizzle that keeps both sides
     // conflict-free.
-    static_assert((NB == 1 || NB == 2) && WAVES == 4, "the LDS transpose uses one quarter of the 4*CHB ring area per wave, one 32-row block at a time");
+    static_assert((NB == 1 || NB == 2) && WAVES % 4 == 0, "every wave transposes its tiles through its own 32-row stage, one block at a time");
     constexpr int CPR = C / 8;               // 16-B chunks per row
     constexpr int NL = 32 * CPR / 64;        // coalesced 16-B loads per lane for one 32-row tile (== KS)
-    char* stage = smem + wave * (32 * C * 2);
+    char* stage = smem + STAGE0 + wave * (32 * C * 2);
     const size_t tile_b = (size_t)row0 * C * 2, last_b = (size_t)M * C * 2 - 16;     // rows >= M: any valid address (never stored)
-    constexpr bool CIO = C <= 192;           // C = 384: measured slower (register spills in the edges, serialised W1[0] DMA)
     constexpr size_t BLK_B = (size_t)32 * C * 2;      // bytes of one 32-row block (contiguous in HBM)
     if constexpr (CIO) {
         u32x4 t[NB][NL];
@@ -399,13 +483,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
         for (int ks = 0; ks < KS; ++ks) afr[nb][ks] = *(const bf16x8*)(arow + ks * 16);
     }
     }
-    if constexpr (CIO) __syncthreads();      // every wave has its fragments: the rings may now receive weights
-#pragma unroll
-    for (int g = 0; g < (NG + WAVES - 1) / WAVES; ++g) {             // W1[0]
-        const int piece = g * WAVES + uwave;
-        if (NG % WAVES == 0 || piece < NG)
-            glds16(w1img + piece * 1024 + lane * 16, lds_w1 + piece * 1024);
-    }
+    if constexpr (CIO && STAGE0 == 0) __syncthreads();      // every wave has its fragments: the rings may now receive weights
+    if constexpr (!(CIO && STAGE0 != 0)) { FFN_W1_FIRST() }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -531,6 +610,294 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 
 #undef FFN_SYNC
 
+// =====================================================================================================================
+// C = 384, half-precision form: WAVE PAIRS (round 4).  With 32 rows per wave every weight fragment read from LDS
+// (1 KiB per wave) feeds ONE MFMA, and 64 rows per wave do not fit the register file at C = 384 (A^T 192 + O^T 384).  Here two waves
+// share 64 rows (two 32-row blocks) and split the two GEMMs the other way:
+//   GEMM1 by K: wave r of the pair holds A^T[k-steps 12 r .. 12 r + 11] of BOTH blocks (96 registers) and computes the partial
+//               S_r^T[32 h x 64 rows] of its K half - 12 W1 fragments, each feeding two MFMAs;
+//   exchange:   a wave keeps the partial of its OWN block (block r) and passes the other one to its partner through LDS (4 KiB);
+//               the next iteration adds the partner's partial of its own block and runs the GELU on that block only;
+//   GEMM2 by N: wave r holds O^T[channels 192 r .. 192 r + 191] of BOTH blocks (192 registers); it needs P of both blocks: its own
+//               from registers, the partner's through LDS (2 KiB) - 12 W2 fragments, each feeding two MFMAs.
+// Per wave and chunk: 48 MFMAs as before, but 24 fragment reads + 6 KiB of exchange reads instead of 48 fragment reads
+// (LDS read traffic 30 KiB instead of 48 KiB), and half the GELU work per wave is unchanged (16 values per lane).  The exchange is
+// double-buffered by iteration parity and published by the one barrier per chunk the weight ring already needs; the pipeline skew
+// (GEMM1(t) | reduce + GELU(t-1) | GEMM2(t-2)) is the one of ffn_iter.  "Own block" is always index 0 of a wave's register arrays.
+#ifndef FVHD_FFN_PAIR384
+#define FVHD_FFN_PAIR384 1
+#endif
+template <bool DO_A, bool DO_B, bool DO_C, bool DO_DMA>
+FVHD_DEV void ffn_pair_iter(const bf16x8 (&afr)[2][12], f32x16 (&o)[2][6], f32x16 (&s_out)[2], const f32x16& s_prev, bf16x8 (&p_out)[2],
+                            const bf16x8 (&p_own)[2], const char* const (&w1p)[8], const char* const (&w2p)[2], const int ring,
+                            const float* b1_cur, int half, const char* xs_rd, char* xs_wr, const char* px_rd, char* px_wr,
+                            const char* dma_src1, unsigned dma_dst1, bool dma1, const char* dma_src2, unsigned dma_dst2, bool dma2, int uwave)
+{
+    constexpr int C = 384, CHB = 64 * C, NG = CHB / 1024, NFRG = 24, NM = 48, PF = 2;
+    // fragment j: j < 12 -> W1, this wave's k-step j;  j >= 12 -> W2 fragment g = j - 12 (n-fragment g >> 1 of this wave's six, k-step g & 1)
+#define FFP_LD(j) ((j) < 12 ? *(const bf16x8*)(w1p[(j) % 8] + ring * CHB + ((j) / 8) * 256)                                  \
+                            : *(const bf16x8*)(w2p[((j) - 12) & 1] + ring * CHB + (((j) - 12) >> 1) * 2048))
+#define FFP_ON(j) ((j) < 12 ? DO_A : DO_C)
+    bf16x8 wf[NFRG];
+    f32x4 bv[4];
+    f32x4 xs[4];                     // the partner's partial S(t-1) of this wave's own block
+    bf16x8 pp[2];                    // the partner's P(t-2) (its own block = block 1 here)
+    f32x16 sf;                       // S(t-1) of the own block, complete
+    GeluSt16 gs16[8];
+    f16x2 gout16[8];
+    if constexpr (DO_A) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = *(const f32x4*)(b1_cur + 8 * q + 4 * half);       // (the second wave of a pair reads zeros)
+    }
+    if constexpr (DO_B) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xs[q] = *(const f32x4*)(xs_rd + q * 1024);
+    }
+    if constexpr (DO_C) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) pp[k] = *(const bf16x8*)(px_rd + k * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (FFP_ON(j)) wf[j] = FFP_LD(j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int j = m >> 1, nb = m & 1;
+        if (j < 12) {
+            if constexpr (DO_A) {
+                if (j == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = bv[r >> 2][r & 3];
+                    s_out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], afr[nb][j], z, 0, 0, 0);
+                } else s_out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], afr[nb][j], s_out[nb], 0, 0, 0);
+            }
+        } else {
+            if constexpr (DO_C) {
+                const int g = j - 12;
+                const bf16x8 pb = nb == 0 ? p_own[g & 1] : pp[g & 1];
+                o[nb][g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[j]), __builtin_bit_cast(f16x8, pb), o[nb][g >> 1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the MFMA opens the slot; everything below issues in its shadow
+        if (nb == 0 && j + PF < NFRG && FFP_ON(j + PF)) wf[j + PF] = FFP_LD(j + PF);
+        if constexpr (DO_DMA) {                 // next iteration's weight images: three runs of four 1-KiB pieces per wave (see ffn_iter)
+            if (m % 8 == 0 && m / 8 < 3) {
+                const int second = uwave >> 1;
+                const unsigned pc0 = (unsigned)((uwave & 1) * 12 + (m / 8) * 4) * 1024u;
+                const char* sb = (second ? dma_src2 : dma_src1) + pc0;
+                const unsigned dst = (second ? dma_dst2 : dma_dst1) + pc0;
+                if (second ? dma2 : dma1) glds16_run<4>(sb, (threadIdx.x & 63) * 16u, dst);
+            }
+        }
+        if constexpr (DO_B) {
+            // reduce: S(t-1) = own partial + the partner's (4 scalar adds per slot in slots 3..6: the exchange reads were issued at the top);
+            // then the ten GELU stages of the pair groups {0,1} {2,3} {4,5} {6,7}: stage k of group g in slot 7 + 10 g + k
+            if (m >= 3 && m < 7) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sf[4 * (m - 3) + i] = s_prev[4 * (m - 3) + i] + xs[m - 3][i];
+            }
+            if (m >= 7 && m < 47) {
+                const int g = (m - 7) / 10, k = (m - 7) % 10;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pr = 2 * g + i, r = 2 * pr;
+                    const f32x2 sv = {sf[r], sf[r + 1]};
+                    gelu16_dispatch(k, gs16[pr], sv, gout16[pr]);
+                    if (k == 9) {
+                        f16x8 pt = __builtin_bit_cast(f16x8, p_out[r >> 3]);
+                        pt[r & 7] = gout16[pr][0];
+                        pt[(r & 7) + 1] = gout16[pr][1];
+                        p_out[r >> 3] = __builtin_bit_cast(bf16x8, pt);
+                    }
+                }
+            }
+        }
+        if constexpr (DO_A) {                   // the partner's block: its partial is complete after slot 23; handed over in slots 26..29
+            if (m >= 26 && m < 30) *(f32x4*)(xs_wr + (m - 26) * 1024) = f32x4{s_out[1][4 * (m - 26)], s_out[1][4 * (m - 26) + 1], s_out[1][4 * (m - 26) + 2], s_out[1][4 * (m - 26) + 3]};
+        }
+        if constexpr (DO_B) {                   // P(t-1) of the own block for the partner's GEMM2 two iterations on
+            if (m == 47) {
+                *(bf16x8*)(px_wr) = p_out[0];
+                *(bf16x8*)(px_wr + 1024) = p_out[1];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (DO_B) asm volatile("" : "+v"(p_out[0]), "+v"(p_out[1]));
+    if constexpr (DO_A) asm volatile("" : "+v"(s_out[0]));
+#undef FFP_LD
+#undef FFP_ON
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_pair384_kernel(
+    const bf16* __restrict__ A, const char* __restrict__ w1img, const char* __restrict__ w2img,
+    const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ ls, bf16* X, int M, int nwg)
+{
+    constexpr int C = 384, HID = 4 * C, NCH = HID / 32, CHB = 64 * C, NG = CHB / 1024, CPR = C / 8, NL = 32 * CPR / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [W1 ring 2 CHB][W2 ring 2 CHB][48 KiB: second half of the tile stage / the exchange buffers][b1 / 4][32 zeros]
+    char* w1ring = smem;
+    char* w2ring = smem + 2 * CHB;
+    char* xbase = smem + 4 * CHB;                                  // X[wave][parity] 4 KiB each, then PX[wave][parity] 2 KiB each
+    float* lb1 = (float*)(smem + 4 * CHB + 49152);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int role = wave & 1;
+    const int blk = xcd_remap(blockIdx.x, nwg);
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_w1 = __builtin_amdgcn_readfirstlane(lds_addr(w1ring)), lds_w2 = __builtin_amdgcn_readfirstlane(lds_addr(w2ring));
+    for (int i = tid; i < HID / 4 + 8; i += 256)
+        *(f32x4*)&lb1[i * 4] = i < HID / 4 ? *(const f32x4*)&b1[i * 4] * 0.25f : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG / 4; ++g) glds16(w1img + (g * 4 + uwave) * 1024 + lane * 16, lds_w1 + (g * 4 + uwave) * 1024);     // W1[0]
+
+    // per-lane fragment pointers: W1 k-step ks (local) = global k-step 12 role + ks, 16-B slot 2 (12 role + ks) + half of row li;
+    // w1p[j] serves local k-steps j and j + 8 (immediate + 256), see the derivation at the call; W2 n-fragment 6 role + nf'
+    const char* w1p[8];
+    const char* w2p[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ksg = 12 * role + j;                              // global k-step of local k-step j
+        w1p[j] = w1ring + w1_off<C>(li, 2 * ksg + half);            // (local k-step j + 8 = global ksg + 8: slot + 16 = + 256 B, same XOR key)
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w2p[k] = w2ring + w2_off(li, 2 * k + half) + role * (6 * 2048);
+
+    // ---- A^T: every wave reads the tile of its own block whole lines at a time into its stage; after a barrier it takes its K half
+    // of both blocks (own block from its own stage, the partner's block from the partner's)
+    const int row_own = blk * 128 + (wave >> 1) * 64 + role * 32;
+    char* stage_own = smem + 2 * CHB + wave * (32 * C * 2);
+    char* stage_par = smem + 2 * CHB + (wave ^ 1) * (32 * C * 2);
+    const size_t tile_b = (size_t)row_own * C * 2, last_b = (size_t)M * C * 2 - 16;
+    {
+        u32x4 t[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const size_t gb = tile_b + (size_t)(i * 64 + lane) * 16;
+            t[i] = *(const u32x4*)((const char*)A + (gb < last_b ? gb : last_b));
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) *(u32x4*)(stage_own + ffn_slot_of<C>(i * 64 + lane)) = t[i];
+    }
+    __syncthreads();
+    bf16x8 afr[2][12];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) {
+        afr[0][ks] = *(const bf16x8*)(stage_own + ffn_slot_of<C>(li * CPR + (12 * role + ks) * 2 + half));
+        afr[1][ks] = *(const bf16x8*)(stage_par + ffn_slot_of<C>(li * CPR + (12 * role + ks) * 2 + half));
+    }
+    f32x16 o[2][6];
+    f32x16 sA[2], sB[2];
+    bf16x8 pA[2], pB[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nb][i][r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sA[nb][r] = 0.f; sB[nb][r] = 0.f; }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { pA[0][r] = 0; pA[1][r] = 0; pB[0][r] = 0; pB[1][r] = 0; }
+
+    // exchange slots (per lane): iteration t writes X / PX [own wave][t & 1] and reads X / PX [partner][(t - 1) & 1]
+    char* x_mine = xbase + wave * 8192 + lane * 16;
+    const char* x_part = xbase + (wave ^ 1) * 8192 + lane * 16;
+    char* px_mine = xbase + 32768 + wave * 4096 + lane * 16;
+    const char* px_part = xbase + 32768 + (wave ^ 1) * 4096 + lane * 16;
+    const float* b1base = role ? lb1 + HID : lb1;                  // second wave of the pair: zeros (the bias enters the sum once)
+    const int b1step = role ? 0 : 32;
+#define FFP_DMA(t) w1img + (size_t)((t) < NCH ? (t) + 1 : 0) * CHB, lds_w1 + (((t) + 1) & 1) * CHB, (t) < NCH, \
+                   w2img + (size_t)((t) >= 1 ? (t) - 1 : 0) * CHB, lds_w2 + (((t) + 1) & 1) * CHB, (t) >= 1, uwave
+#define FFP_X(t) x_part + (((t) + 1) & 1) * 4096, x_mine + ((t) & 1) * 4096, px_part + (((t) + 1) & 1) * 2048, px_mine + ((t) & 1) * 2048
+#define FFP_SYNC() ffn_wait_dma(); __syncthreads()
+    FFP_SYNC();
+    ffn_pair_iter<true, false, false, true>(afr, o, sA, sB[0], pB, pA, w1p, w2p, 0, b1base, half, FFP_X(0), FFP_DMA(0));
+    FFP_SYNC();
+    ffn_pair_iter<true, true, false, true>(afr, o, sB, sA[0], pA, pB, w1p, w2p, 1, b1base + b1step, half, FFP_X(1), FFP_DMA(1));
+#pragma unroll 1
+    for (int t = 2; t < NCH; t += 2) {
+        FFP_SYNC();                  // even t: S(t) -> sA, reduce + GELU(sB) -> pB, GEMM2 reads pA (own) and the partner's P(t-2)
+        ffn_pair_iter<true, true, true, true>(afr, o, sA, sB[0], pB, pA, w1p, w2p, 0, b1base + t * b1step, half, FFP_X(t), FFP_DMA(t));
+        FFP_SYNC();
+        ffn_pair_iter<true, true, true, true>(afr, o, sB, sA[0], pA, pB, w1p, w2p, 1, b1base + (t + 1) * b1step, half, FFP_X(t + 1), FFP_DMA(t + 1));
+    }
+    // residual tile of the own block, whole lines (the A^T registers are dead from here on)
+    u32x4 xq[NL];
+    {
+        int xln = lane;
+        asm volatile("" : "+v"(xln));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const size_t gb = tile_b + (size_t)(i * 64 + xln) * 16;
+            xq[i] = *(const u32x4*)((const char*)X + (gb < last_b ? gb : last_b));
+        }
+    }
+    FFP_SYNC();                      // t = NCH (even): reduce + GELU(S(NCH-1) in sB) -> pB, GEMM2(chunk NCH-2) reads pA; DMA W2[NCH-1]
+    ffn_pair_iter<false, true, true, true>(afr, o, sA, sB[0], pB, pA, w1p, w2p, 0, b1base, half, FFP_X(NCH), FFP_DMA(NCH));
+    FFP_SYNC();                      // t = NCH + 1: GEMM2(chunk NCH-1) reads pB and the partner's
+    ffn_pair_iter<false, false, true, false>(afr, o, sB, sA[0], pA, pB, w1p, w2p, 1, b1base, half, FFP_X(NCH + 1), FFP_DMA(NCH));
+#undef FFP_DMA
+#undef FFP_X
+#undef FFP_SYNC
+
+    // ---- epilogue: both waves of a pair hold channels 192 role .. + 191 of BOTH blocks.  Every wave puts the residual tile of its own
+    // block into its stage; after a barrier each wave updates its channel half in its own and in the partner's stage
+    // (x + ls * (o + b2), one rounding to bf16); after another barrier every wave stores its own block as whole lines.
+    __syncthreads();
+    int eln = lane;
+    asm volatile("" : "+v"(eln));
+    const int eli = eln & 31, ehalf = eln >> 5;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *(u32x4*)(stage_own + ffn_slot_of<C>(i * 64 + eln)) = xq[i];
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        char* stg = nb == 0 ? stage_own : stage_par;
+#pragma unroll
+        for (int nf = 0; nf < 6; ++nf)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = (6 * role + nf) * 32 + 8 * q + 4 * ehalf;
+                char* slot = stg + ffn_slot_of<C>(eli * CPR + (6 * role + nf) * 4 + q) + ehalf * 8;
+                const f32x4 bv = *(const f32x4*)(b2 + n0), lv = *(const f32x4*)(ls + n0);
+                const f32x4 rv = bf4_to_f32(*(const bf16x4*)slot);
+                f32x4 v;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) v[jj] = rv[jj] + lv[jj] * (o[nb][nf][4 * q + jj] + bv[jj]);
+                *(bf16x4*)slot = f32_to_bf4(v);
+            }
+    }
+    __syncthreads();
+    const int rows_ok = M - row_own;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int id = i * 64 + eln;
+        const u32x4 v = *(const u32x4*)(stage_own + ffn_slot_of<C>(id));
+        if (id < rows_ok * CPR) *(u32x4*)((char*)X + tile_b + (size_t)id * 16) = v;
+    }
+}
+
+static hipError_t launch_ffn_pair384(hipStream_t st, const bf16* A, const char* w1img, const char* w2img, const float* b1,
+                                     const float* b2, const float* ls, bf16* X, int M)
+{
+    const int nwg = (M + 127) / 128;
+    const size_t shmem = (size_t)4 * 64 * 384 + 49152 + (size_t)4 * 384 * 4 + 128 + 256;
+    static bool attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)ffn_pair384_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(ffn_pair384_kernel, dim3(nwg), dim3(256), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
+    return hipGetLastError();
+}
+
 template <typename K> static hipError_t ffn_set_lds(K kernel, size_t shmem, bool* done)
 {
     int dev = 0;
@@ -547,7 +914,8 @@ static hipError_t launch_ffn(hipStream_t st, const bf16* A, const char* w1img, c
 {
     constexpr int ROWS = 32 * NB * WAVES;
     const int nwg = (M + ROWS - 1) / ROWS;
-    const size_t shmem = (size_t)4 * 64 * C + (size_t)4 * C * 4 + 256;
+    const size_t rings = (size_t)4 * 64 * C, stage_end = (C == 384 ? (FVHD_FFN_CIO384 ? (size_t)2 * 64 * C : 0) : 0) + ((C <= 192 || FVHD_FFN_CIO384) ? (size_t)WAVES * 32 * C * 2 : 0);
+    const size_t shmem = (stage_end > rings ? stage_end : rings) + (size_t)4 * C * 4 + 256;
     static bool attr_set[64];                // the attribute is per device
     hipError_t e = ffn_set_lds(ffn_fused_kernel<C, NB, WAVES, VAR, PF, OCC, F16>, shmem, attr_set);
     if (e != hipSuccess) return e;
@@ -670,7 +1038,16 @@ extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* 
 #ifndef FVHD_FFN_NB96
 #define FVHD_FFN_NB96 1
 #endif
-    if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
+#ifndef FVHD_FFN_W192
+#define FVHD_FFN_W192 4              // waves per workgroup at C = 192 (8: 256 rows share one weight stream, one workgroup per CU, still two waves per SIMD)
+#endif
+#ifndef FVHD_FFN_W96
+#define FVHD_FFN_W96 4               // ... at C = 96 (12: 384 rows per workgroup, three waves per SIMD)
+#endif
+    if (C == 384 && FVHD_FFN_PAIR384) e = launch_ffn_pair384(st, a, w1, w2, b1, b2, ls, x, M);
+    else if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
+    else if (C == 192 && FVHD_FFN_W192 == 8) e = launch_ffn<192, 1, 8, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
+    else if (C == 96 && FVHD_FFN_W96 == 12) e = launch_ffn<96, 1, 12, 0, 3, 3>(st, a, w1, w2, b1, b2, ls, x, M);
     else if (C == 192 && FVHD_FFN_NB192 == 2) e = launch_ffn<192, 2, 4, 0, 3, 1>(st, a, w1, w2, b1, b2, ls, x, M);
     else if (C == 96 && FVHD_FFN_NB96 == 2) e = launch_ffn<96, 2, 4, 0, 3, FVHD_FFN_OCC96>(st, a, w1, w2, b1, b2, ls, x, M);
     else if (C == 192) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);

@@ -57,7 +57,7 @@ extern "C" int fvhd_launch_rmsnorm(hipStream_t st, const void* x, void* y, const
 // to the KV cache [B][nkv][T][HD] (the layout of transformers' DynamicCache layers) for a decode loop to continue from.
 __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const long* __restrict__ pos, const float* __restrict__ table,
                                                    bf16* __restrict__ kcache, bf16* __restrict__ vcache, int M, int T, int nh, int nkv, int HD, int P,
-                                                   float neg_log2_theta_2_over_hd)
+                                                   float theta)
 {
     const int per_head = HD / 8;                                 // threads per head: 4 i's each, HD / 2 i's
     const int nheads = nh + nkv + (vcache ? nkv : 0);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const
         float cs[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float inv = exp2f((float)(i4 + k) * neg_log2_theta_2_over_hd);
+            const float inv = 1.0f / powf(theta, (float)(2 * (i4 + k)) / (float)HD);      // the host's expression for the table rows
             const float ang = (float)p * inv;
             cs[2 * k] = cosf(ang);
             cs[2 * k + 1] = sinf(ang);
@@ -123,7 +123,7 @@ extern "C" int fvhd_launch_rope(hipStream_t st, void* qkv, const long* pos, cons
     if (M <= 0 || T <= 0 || nh <= 0 || nkv <= 0 || HD % 8 || P <= 0 || !(theta > 0.f) || (kcache == nullptr) != (vcache == nullptr)) return (int)hipErrorInvalidValue;
     const long total = (long)M * (nh + nkv + (vcache ? nkv : 0)) * (HD / 8);
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (bf16*)qkv, pos, table, (bf16*)kcache, (bf16*)vcache,
-                       M, T, nh, nkv, HD, P, -log2f(theta) * 2.0f / (float)HD);
+                       M, T, nh, nkv, HD, P, theta);
     return (int)hipGetLastError();
 }
 

@@ -14,10 +14,11 @@ suite)      # the whole GPU suite + the driver's bench line
     timeout 600 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cut -c1-600 ${O}_bench.json
     ;;
 ffn)        # fused ConvFFN variants: correctness of the variant library, sustained time / power / energy per launch, whole step
-    for lib in "" nb2; do
+    for lib in ${FFN_LIBS:-"" old}; do
+        [ "$lib" = base ] && lib=""
         L=ml_fastvlm_amd/libfvhd${lib:+_$lib}.so
         [ -f $L ] || { echo "missing $L"; continue; }
-        [ -n "$lib" ] && FVHD_LIB=$L timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "ffn" > ${O}_ffn_${lib}_pytest.log 2>&1 && tail -1 ${O}_ffn_${lib}_pytest.log
+        FVHD_LIB=$L timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "ffn" > ${O}_ffn_${lib:-base}_pytest.log 2>&1; tail -1 ${O}_ffn_${lib:-base}_pytest.log
         FVHD_LIB=$L timeout 300 python tools/power_probe.py ffn384 ffn192 ffn96 2>/dev/null | tee -a ${O}_ffn_power.log
         FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_${lib:-base}.json 2>/dev/null; python - <<PY
 import json
@@ -29,6 +30,9 @@ extra)      # the other BASELINE configs: TTFT at the 7B width, 1536^2 with bf16
     timeout 600 python bench.py --ttft --hidden 3584 --steps 10 --warmup 2 > ${O}_ttft_h3584.json 2> ${O}_ttft_h3584.err; echo "ttft3584 rc=$?"; cut -c1-400 ${O}_ttft_h3584.json
     timeout 400 python bench.py --res 1536 --batch 16 --no-cpu-baseline --no-ttft > ${O}_bench_1536.json 2>/dev/null; echo "1536 rc=$?"; cut -c1-300 ${O}_bench_1536.json
     timeout 400 python bench.py --res 1536 --batch 16 --attn-fp8 --no-cpu-baseline --no-ttft > ${O}_bench_1536_fp8.json 2>/dev/null; echo "1536 fp8 rc=$?"; cut -c1-300 ${O}_bench_1536_fp8.json
+    ;;
+rest)       # the GPU tests a -x run did not reach + one named file
+    timeout 900 python -m pytest ${REST_TESTS:-tests/test_qwen2_prefill.py tests/test_splice.py tests/test_preprocess.py} -m gpu -x -q > ${O}_pytest_rest.log 2>&1; echo "pytest rest rc=$?"; tail -3 ${O}_pytest_rest.log
     ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
