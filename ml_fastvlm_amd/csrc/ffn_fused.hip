@@ -624,9 +624,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(OCC,
 // (LDS read traffic 30 KiB instead of 48 KiB), and half the GELU work per wave is unchanged (16 values per lane).  The exchange is
 // double-buffered by iteration parity and published by the one barrier per chunk the weight ring already needs; the pipeline skew
 // (GEMM1(t) | reduce + GELU(t-1) | GEMM2(t-2)) is the one of ffn_iter.  "Own block" is always index 0 of a wave's register arrays.
+// MEASURED (profiles/r04_ffn_pair384_power.log, same box, sustained): correct (all fused-FFN op tests), and SLOWER - 324 us against 304 us
+// per launch for the one-block-per-wave kernel with the same round-4 changes, 422 against 393 mJ; the chip answers with a higher clock
+// (2.05 against 1.79 GHz) but the pair needs 22 % more cycles: the LDS traffic it saves was not what the loop waited for, and the two
+// exchanges put an LDS round trip and the partner's progress into every chunk's dependency chain.  Compiled only with
+// -DFVHD_FFN_PAIR384=1 (kept as the record of the experiment; the shipped library does not contain it).
 #ifndef FVHD_FFN_PAIR384
-#define FVHD_FFN_PAIR384 1
+#define FVHD_FFN_PAIR384 0
 #endif
+#if FVHD_FFN_PAIR384
 template <bool DO_A, bool DO_B, bool DO_C, bool DO_DMA>
 FVHD_DEV void ffn_pair_iter(const bf16x8 (&afr)[2][12], f32x16 (&o)[2][6], f32x16 (&s_out)[2], const f32x16& s_prev, bf16x8 (&p_out)[2],
                             const bf16x8 (&p_own)[2], const char* const (&w1p)[8], const char* const (&w2p)[2], const int ring,
@@ -897,6 +903,7 @@ static hipError_t launch_ffn_pair384(hipStream_t st, const bf16* A, const char* 
     hipLaunchKernelGGL(ffn_pair384_kernel, dim3(nwg), dim3(256), shmem, st, A, w1img, w2img, b1, b2, ls, X, M, nwg);
     return hipGetLastError();
 }
+#endif   // FVHD_FFN_PAIR384
 
 template <typename K> static hipError_t ffn_set_lds(K kernel, size_t shmem, bool* done)
 {
@@ -1044,12 +1051,25 @@ extern "C" int fvhd_launch_ffn_fused(hipStream_t st, const void* A, const void* 
 #ifndef FVHD_FFN_W96
 #define FVHD_FFN_W96 4               // ... at C = 96 (12: 384 rows per workgroup, three waves per SIMD)
 #endif
-    if (C == 384 && FVHD_FFN_PAIR384) e = launch_ffn_pair384(st, a, w1, w2, b1, b2, ls, x, M);
-    else if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
-    else if (C == 192 && FVHD_FFN_W192 == 8) e = launch_ffn<192, 1, 8, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
-    else if (C == 96 && FVHD_FFN_W96 == 12) e = launch_ffn<96, 1, 12, 0, 3, 3>(st, a, w1, w2, b1, b2, ls, x, M);
-    else if (C == 192 && FVHD_FFN_NB192 == 2) e = launch_ffn<192, 2, 4, 0, 3, 1>(st, a, w1, w2, b1, b2, ls, x, M);
-    else if (C == 96 && FVHD_FFN_NB96 == 2) e = launch_ffn<96, 2, 4, 0, 3, FVHD_FFN_OCC96>(st, a, w1, w2, b1, b2, ls, x, M);
+#if FVHD_FFN_PAIR384
+    if (C == 384) e = launch_ffn_pair384(st, a, w1, w2, b1, b2, ls, x, M);
+    else
+#endif
+    if (C == 384) e = launch_ffn<384, 1, 4>(st, a, w1, w2, b1, b2, ls, x, M);
+    // measured alternatives, compiled only on request (profiles/r04_ffn_nb2_power.log, r04_ffn_pairwait_cio384_w8_power.log): 64 rows per
+    // wave (NB 2) 341 -> 356 us at C = 192, 455 -> 524 at C = 96; 8- / 12-wave workgroups sharing one weight stream 342 -> 352 / 463 -> 487
+#if FVHD_FFN_W192 == 8
+    else if (C == 192) e = launch_ffn<192, 1, 8, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
+#endif
+#if FVHD_FFN_W96 == 12
+    else if (C == 96) e = launch_ffn<96, 1, 12, 0, 3, 3>(st, a, w1, w2, b1, b2, ls, x, M);
+#endif
+#if FVHD_FFN_NB192 == 2
+    else if (C == 192) e = launch_ffn<192, 2, 4, 0, 3, 1>(st, a, w1, w2, b1, b2, ls, x, M);
+#endif
+#if FVHD_FFN_NB96 == 2
+    else if (C == 96) e = launch_ffn<96, 2, 4, 0, 3, FVHD_FFN_OCC96>(st, a, w1, w2, b1, b2, ls, x, M);
+#endif
     else if (C == 192) e = launch_ffn<192, 1, 4, 0, 3, 2>(st, a, w1, w2, b1, b2, ls, x, M);
     // C = 96: 152 registers since the epilogue offsets stopped being hoisted -> three workgroups (waves) per SIMD: the kernel is
     // VALU-issue-bound (16 GELUs per 12 MFMAs), a third instruction stream per SIMD is what it needs
