@@ -54,11 +54,12 @@ def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True):
         add(k, 2.0 * M * N * K, 2.0 * (M * K + M * N * (2 if resid else 1) + N * K))
 
     H = R // 2
-    # dense 3x3 s2 + dw 3x3 s2 in one launch: the [B, R/2, R/2, 96] intermediate never reaches HBM (1.13x halo recompute
+    # convolutional_stem in one launch: neither intermediate ([B, R/2, R/2, 96], [B, R/4, R/4, 96]) reaches HBM (1.13x halo recompute
     # of the dense conv is not counted: algorithmic figures)
     add("stem", 2.0 * B * H * H * 96 * 27 + 2.0 * B * (H // 2) ** 2 * 96 * 9, B * (3 * R * R * 2 + (H // 2) ** 2 * 96 * 2))
     H //= 2
-    gemm("stem", B * H * H, 96, 96)
+    # stem[2] (1x1 + GELU) runs in the same launch since round 4: its FLOPs and weights count, its input / output tensor does not exist in HBM
+    add("stem", 2.0 * B * H * H * 96 * 96, 2.0 * 96 * 96)
     for s, (C, depth) in enumerate(zip(spec.EMBED_DIMS, spec.LAYERS)):
         M = B * H * H
         if spec.HAS_CPE[s]:

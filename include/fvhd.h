@@ -189,11 +189,12 @@ int fvhd_op_attention(fvhd_stream_t stream, const void* qkv, void* out, int B, i
 int fvhd_op_attention_fp8(fvhd_stream_t stream, const void* qkv, void* out, int B, int N, int C);
 /* stem[0] (mci.py:563-574): img [B,3,R,R] of dtype -> out [B,R/2,R/2,96] bf16; w fp32 [27][96] (k = ci*9+ky*3+kx). */
 int fvhd_op_stem_conv(fvhd_stream_t stream, const void* img, int dtype, void* out, const float* w, const float* bias, int B, int R);
-/* stem[0] + stem[1] in one launch (mci.py:563-586): img [B,3,R,R] of dtype -> out [B,R/4,R/4,96] bf16;
- * w0 fp32 [27][96], b0 [96] as fvhd_op_stem_conv; w1 fp32 [9][96] (tap-major), b1 [96] as fvhd_op_dwconv(K=3, stride 2, gelu).
- * Bit-identical to fvhd_op_stem_conv followed by that fvhd_op_dwconv. */
+/* convolutional_stem in one launch (mci.py:553-603): img [B,3,R,R] of dtype -> out [B,R/4,R/4,96] bf16;
+ * w0 fp32 [27][96], b0 [96] as fvhd_op_stem_conv; w1 fp32 [9][96] (tap-major), b1 [96] as fvhd_op_dwconv(K=3, stride 2, gelu);
+ * w2 bf16 [96][96] ([out][in], as fvhd_op_gemm takes weights), b2 fp32 [96]: stem[2], the 1x1 conv + GELU (mci.py:587-598) - or both
+ * NULL: stem[0] + stem[1] only.  Bit-identical to fvhd_op_stem_conv -> fvhd_op_dwconv [-> fvhd_op_gemm(FVHD_EPI_BIAS_GELU)]. */
 int fvhd_op_stem_fused(fvhd_stream_t stream, const void* img, int dtype, void* out, const float* w0, const float* b0,
-                       const float* w1, const float* b1, int B, int R);
+                       const float* w1, const float* b1, const void* w2, const float* b2, int B, int R);
 /* SEBlock + GELU of conv_exp (mci.py:72-81,198): y [B,T,C] bf16 -> out [B,T,C] of out_dtype;
  * pooled: fp32 scratch [B*(C+RD)]; scale: fp32 scratch [B,C]; wr fp32 [RD][C]; we fp32 [C][RD]; RD % 4 == 0. */
 int fvhd_op_se_head(fvhd_stream_t stream, const void* y, float* pooled, float* scale, const float* wr, const float* br,

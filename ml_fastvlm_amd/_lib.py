@@ -55,7 +55,7 @@ def _declare(lib) -> None:
         "fvhd_set_graph": (ci, [vp, ci]),
         "fvhd_set_batch_invariant": (ci, [vp, ci]),
         "fvhd_op_stem_conv": (ci, [vp, vp, ci, vp, vp, vp, ci, ci]),
-        "fvhd_op_stem_fused": (ci, [vp, vp, ci, vp, vp, vp, vp, vp, ci, ci]),
+        "fvhd_op_stem_fused": (ci, [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci]),
         "fvhd_op_se_head": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
         "fvhd_op_ffn_fused": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]),
         "fvhd_ffn_fused_supported": (ci, [ci]),

@@ -22,7 +22,7 @@ int fvhd_launch_preprocess(hipStream_t, const void*, int, int, long, int, int, u
 int fvhd_dw7_mfma_supported(int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
-int fvhd_launch_stem_fused(hipStream_t, const void*, int, void*, const float*, const float*, const float*, const float*, int, int);
+int fvhd_launch_stem_fused(hipStream_t, const void*, int, void*, const float*, const float*, const float*, const float*, const void*, const float*, int, int);
 int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int, int);
 int fvhd_launch_stem_conv(hipStream_t, const void*, int, void*, const float*, const float*, int, int);
 int fvhd_launch_se_head(hipStream_t, const void*, float*, float*, const float*, const float*, const float*, const float*,
@@ -146,7 +146,9 @@ struct fvhd_ctx {
     size_t ws_bytes = 0;
     int ws_batch = 0, ws_hidden = 0;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
-    bool use_fused_stem = true;  // FVHD_FUSED_STEM=0: stem[0] and stem[1] as two launches through a [B,R/2,R/2,96] HBM tensor
+    // FVHD_FUSED_STEM: 2 (default) the whole convolutional_stem in ONE launch; 1: stem[0] + stem[1] fused, stem[2] as a GEMM launch (rounds
+    // 1-3); 0: three launches through a [B,R/2,R/2,96] HBM tensor.  All three give the same bits.
+    int use_fused_stem = 2;
     int attn_fp8 = 0;            // fvhd_set_attention_fp8 / FVHD_ATTN_FP8=1: e4m3 MFMA operands in MHSA (BASELINE.json configs[4]; opt-in)
     int batch_invariant = 0;     // fvhd_set_batch_invariant: kernel choice by image shape only (bit-identical rows in any batch)
     // fvhd_audit_ranges: while set, every ConvFFN also runs its fc1 as a plain GEMM (bias, no GELU) and reduces max |fc1 out| into
@@ -457,11 +459,18 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
     int e;
     switch (sp.kind) {
     case S_STEM: {   // convolutional_stem (mci.py:553-603)
+        if (c->use_fused_stem == 2) {
+            Scope s(c, st, C_STEM);
+            CHECK_LAUNCH(fvhd_launch_stem_fused(st, images, img_dtype, X, c->wp<float>(m.stem0_w), c->wp<float>(m.stem0_b),
+                                                c->wp<float>(m.stem1.w), c->wp<float>(m.stem1.b), c->wdev + m.stem2.w, c->wp<float>(m.stem2.b), B, R),
+                         "fused stem launch");
+            return 0;
+        }
         if (c->use_fused_stem) {
             {
                 Scope s(c, st, C_STEM);
                 CHECK_LAUNCH(fvhd_launch_stem_fused(st, images, img_dtype, w.A, c->wp<float>(m.stem0_w), c->wp<float>(m.stem0_b),
-                                                    c->wp<float>(m.stem1.w), c->wp<float>(m.stem1.b), B, R),
+                                                    c->wp<float>(m.stem1.w), c->wp<float>(m.stem1.b), nullptr, nullptr, B, R),
                              "fused stem launch");
             }
             return run_gemm(c, st, C_STEM, c->wdev, m.stem2, w.A, nullptr, nullptr, X, B * (R / 4) * (R / 4), FVHD_EPI_BIAS_GELU);
@@ -635,7 +644,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->R = image_size;
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
-    if (const char* ev = getenv("FVHD_FUSED_STEM")) c->use_fused_stem = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_FUSED_STEM")) c->use_fused_stem = atoi(ev);
     if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_GRAPH")) c->graph = atoi(ev) != 0;
     *out = c;
@@ -1053,9 +1062,10 @@ int fvhd_op_stem_conv(fvhd_stream_t st, const void* img, int dtype, void* out, c
 }
 
 int fvhd_op_stem_fused(fvhd_stream_t st, const void* img, int dtype, void* out, const float* w0, const float* b0,
-                       const float* w1, const float* b1, int B, int R)
+                       const float* w1, const float* b1, const void* w2, const float* b2, int B, int R)
 {
-    int e = fvhd_launch_stem_fused((hipStream_t)st, img, dtype, out, w0, b0, w1, b1, B, R);
+    if ((w2 == nullptr) != (b2 == nullptr)) return fail("fvhd_op_stem_fused: w2 and b2 come together");
+    int e = fvhd_launch_stem_fused((hipStream_t)st, img, dtype, out, w0, b0, w1, b1, w2, b2, B, R);
     return e ? hip_fail("fvhd_op_stem_fused", (hipError_t)e) : 0;
 }
 

@@ -192,8 +192,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // MFMAs instead of 8 per 16 (the LDS pipe was the co-bottleneck of v2), 128 accumulator registers per lane, two 64-KB stages (128 KB:
 // one workgroup per CU, two waves per SIMD) - the "256^2 tile, glds, 2 LDS buffers, BK = 64, vmcnt(0) + barrier" structure of
 // cdna_hip_programming.md 5.  Taken when N % 256 == 0 and there are at least two rounds of tiles.
-template <int BN, int BK = 64> struct G2Cfg {
-    static constexpr int RS = BN == 256 ? 2 : 3, STAGE = (256 + BN) * BK * 2, LDS = RS * STAGE;
+// ring depth: K tiles of 64 -> 2 (256 x 256: 2 x 64 KB) or 3 (256 x 128: 3 x 48 KB) stages; K tiles of 32 at 8 waves (round-4 experiment,
+// debug knobs 6 / 7) -> 4 x 32 KB (256 x 256) or 6 x 24 KB (256 x 128) stages: THREE / FIVE tiles of LDS-DMA in flight instead of one / two
+// (the 64-KB stage of the 256 x 256 tile is issued in one burst right after the barrier and waited for at the next one)
+template <int BN, int BK = 64, int NWV = 8> struct G2Cfg {
+    static constexpr int RS = BK == 64 ? (BN == 256 ? 2 : 3) : (NWV == 4 ? 3 : BN == 256 ? 4 : 6), STAGE = (256 + BN) * BK * 2, LDS = RS * STAGE;
 };
 // the XOR key of lds_off<BK> as a function of the row (the LDS-DMA applies it on the global side)
 template <int BK> FVHD_DEV int lds_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); }
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
 {
     // BN = 128, NWV = 8: waves 4 (M) x 2 (N), 64 x 64 each (two per SIMD).  BN = 128, NWV = 4: 2 x 2, 128 x 64 each - 12 instead of 16 fragment
     // reads per 32 MFMAs, one wave per SIMD.  BN = 256, NWV = 8: 2 x 4, 128 x 64 each, two per SIMD.
-    constexpr int BM = 256, BK = BKT, WN = BN / 64, WM = NWV / WN, MF = BM / WM / 16, NF = 4, RS = G2Cfg<BN, BK>::RS, STAGE = G2Cfg<BN, BK>::STAGE;
+    constexpr int BM = 256, BK = BKT, WN = BN / 64, WM = NWV / WN, MF = BM / WM / 16, NF = 4, RS = G2Cfg<BN, BK, NWV>::RS, STAGE = G2Cfg<BN, BK, NWV>::STAGE;
     constexpr int RPP = 1024 / (BK * 2), LPR = BK / 8;        // rows per 1-KiB piece (8 / 16), lanes (16-B chunks) per row (8 / 4)
     constexpr int PA = (BM / RPP) / NWV, PW = (BN / RPP) / NWV;   // 1-KiB pieces of the A / W tile per wave
     static_assert(WM * WN == NWV && MF * 16 * WM == BM, "wave grid");
@@ -264,8 +267,15 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
         if (i < nk) issue(i);
     for (int kt = 0; kt < nk; ++kt) {
         // own pieces of tile kt have landed when at most the RS - 2 later tiles' PA + PW are outstanding (loads only in this loop)
-        if (RS > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RS - 2) * (PA + PW)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (near the end fewer later tiles exist: RS - 2 only while kt + RS - 2 < nk)
+        {
+            const int later = nk - 1 - kt < RS - 2 ? nk - 1 - kt : RS - 2;
+            if (later == RS - 2 && RS > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RS - 2) * (PA + PW)) : "memory");
+            else if (RS > 5 && later == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (PA + PW)) : "memory");
+            else if (RS > 4 && later == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PA + PW)) : "memory");
+            else if (RS > 3 && later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * (PA + PW)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();                              // tile kt visible to every wave; tile kt - 1 fully consumed
         if (kt + RS - 1 < nk) issue(kt + RS - 1);     // into the stage tile kt - 1 occupied
         const char* ldsA = lds2 + (kt % RS) * STAGE;
@@ -415,12 +425,12 @@ static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV, BN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<BN, BKT>::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV, BN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<BN, BKT, NWV>::LDS);
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = true;
     }
     const int tiles_m = M / 256, tiles_n = N / BN, nwg = tiles_m * tiles_n;
-    constexpr int LDSB = G2Cfg<BN, BKT>::LDS;
+    constexpr int LDSB = G2Cfg<BN, BKT, NWV>::LDS;
     hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN, BKT>), dim3(nwg), dim3(64 * NWV), LDSB, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
     return hipGetLastError();
 }
@@ -484,6 +494,24 @@ static hipError_t dispatch_gemm256_2wg(hipStream_t st, const bf16* a, const bf16
     case EPI_BIAS_LS_RESID: return launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
     case EPI_RESID: return launch_gemm256<EPI_RESID, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
     case EPI_SWIGLU: return launch_gemm256<EPI_SWIGLU, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    }
+    return hipErrorInvalidValue;
+}
+#endif
+
+#ifdef FVHD_DEBUG_KNOBS
+// knobs 6 / 7 (experiment, debug library only): the 8-wave 256 x 256 / 256 x 128 tiles with K tiles of 32 and a 4- / 6-stage ring
+template <int BN>
+static hipError_t dispatch_gemm256_bk32(hipStream_t st, const bf16* a, const bf16* w, const float* bias, const float* ls, const bf16* r, void* out,
+                                        int M, int N, int K, int epi)
+{
+    switch (epi) {
+    case EPI_NONE: return launch_gemm256<EPI_NONE, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS: return launch_gemm256<EPI_BIAS, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_GELU: return launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_BIAS_LS_RESID: return launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_RESID: return launch_gemm256<EPI_RESID, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
+    case EPI_SWIGLU: return launch_gemm256<EPI_SWIGLU, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
     }
     return hipErrorInvalidValue;
 }
@@ -572,6 +600,8 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
         const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
 #ifdef FVHD_DEBUG_KNOBS
         if (g_gemm_v2 == 5) return (int)dispatch_gemm256_2wg(st, a, w, bias, ls, r, out, M, N, K, epi);
+        if (g_gemm_v2 == 6 && t256 > 0) return (int)dispatch_gemm256_bk32<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
+        if (g_gemm_v2 == 7 || g_gemm_v2 == 6) return (int)dispatch_gemm256_bk32<128>(st, a, w, bias, ls, r, out, M, N, K, epi);
 #endif
         // measured (tools/bench_ops.py gemm, profiles/r03_gemm_tiles.log, B = 32): the 256 x 256 tile wins from N = 2304 on when it has
         // ~2 rounds of tiles - stage-3 qkv 186 -> 165 us, fc1 268 -> 242, stage-4 fc1 224 -> 204, 7B projector 239 / 267 -> 211 / 239 -

@@ -144,20 +144,29 @@ extern "C" int fvhd_launch_stem_conv(hipStream_t st, const void* img, int dtype,
 #define STEMF_IB (3 * STEMF_IR * STEMF_IS * 2)   // image tile bytes (8400)
 #define STEMF_PS 208                      // bytes per region position in LDS: 96 bf16 + 16 B pad (a 192-B stride put the 16
                                           // lanes of a ds_write_b64 group on 4 banks: 8-way conflicts; 208 leaves 2-way)
-template <typename T>
-__global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ img, bf16* __restrict__ out,
-                                                         const float* __restrict__ w0, const float* __restrict__ b0,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         int B, int R, int ntiles)
+// FULL (round 4): stem[2] - the 1x1 conv 96 -> 96 + bias + GELU (mci.py:587-598) - in the same launch.  Phase 2 leaves its 8 x 8 x 96
+// tile in LDS ([64 px][96] bf16, aliasing the weight image of the kernel's start and the image tile of phase 0, both dead by then)
+// instead of writing it to HBM; phase 3 runs it through 72 MFMAs (v_mfma_f32_16x16x32_bf16, W2 fragments as the A operand so that a
+// lane ends with 4 consecutive output channels of one pixel), bias + GELU, and stores the tile as whole 192-B pixels.  Every wave owns
+// 16 pixels of the tile from the B-operand reads to the store, so the phase needs no barrier of its own; one more barrier at the end
+// of the tile keeps the next tile's phase 0 off the buffer.  The unfused path wrote and re-read a [B, R/4, R/4, 96] tensor (806 MB of
+// HBM traffic per step at B = 32) and cost a GEMM launch.
+template <typename T, bool FULL>
+__global__ __launch_bounds__(256, 2) void stem_fused_kernel(const T* __restrict__ img, bf16* __restrict__ out,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const bf16* __restrict__ w2, const float* __restrict__ b2,
+                                                            int B, int R, int ntiles)
 {
     // Round 3: a workgroup walks STEMF_TPW consecutive tiles (one every gridDim.x) instead of one: the weight fragment image and the
     // stem[1] taps are built once, and the NEXT tile's 3 x 35 x 35 image pixels are loaded into registers while the current tile
     // runs its two phases (one tile per workgroup spent most of its ~15 us waiting for that gather: 32768 workgroups x 3 barriers).
     constexpr int CO = 96;
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
-    bf16x8* wimg = (bf16x8*)smem_f;                              // [cb][s][lane]: 6 KiB
-    float* lw1 = (float*)(smem_f + 6 * 64 * 16);                 // [9][96] fp32 taps of stem[1]
-    bf16* itile = (bf16*)(smem_f + 6 * 64 * 16 + 9 * CO * 4);    // image tile [3][35][STEMF_IS] bf16 (zero outside the image)
+    float* lw1 = (float*)smem_f;                                 // [9][96] fp32 taps of stem[1]
+    bf16x8* wimg = (bf16x8*)(smem_f + 9 * CO * 4);               // [cb][s][lane]: 6 KiB (read once, before the tile loop)
+    bf16* itile = (bf16*)(smem_f + 9 * CO * 4 + 6 * 64 * 16);    // image tile [3][35][STEMF_IS] bf16 (zero outside the image)
+    char* y1 = smem_f + 9 * CO * 4;                              // FULL: stem[1] output tile [64 px][STEMF_PS]; aliases wimg + itile
     char* reg = smem_f + 6 * 64 * 16 + 9 * CO * 4 + STEMF_IB;    // [289][96] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = lane & 31, half = lane >> 5;
@@ -216,6 +225,8 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
     for (int cb = 0; cb < 3; ++cb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[cb][q] = *(const f32x4*)(b0 + cb * 32 + q * 8 + half * 4);
+    static_assert(64 * STEMF_PS <= 6 * 64 * 16 + STEMF_IB, "the stem[1] tile fits into the weight image + image tile it aliases");
+    __syncthreads();                                              // FULL: every wave has its fragments before phase 2 of the first tile overwrites wimg
 
 #pragma unroll 1
     for (; tile < ntiles; tile += gridDim.x) {
@@ -313,15 +324,60 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const T* __restrict__ i
         f32x8 r;
 #pragma unroll
         for (int c = 0; c < 8; ++c) r[c] = gelu_erf(acc[c]);
-        *(bf16x8*)(out + (((size_t)b * H2 + ty * STEMF_T + oy) * H2 + tx * STEMF_T + ox) * CO + cg * 8) = f32_to_bf8(r);
+        if constexpr (FULL) *(bf16x8*)(y1 + pxl * STEMF_PS + cg * 16) = f32_to_bf8(r);
+        else *(bf16x8*)(out + (((size_t)b * H2 + ty * STEMF_T + oy) * H2 + tx * STEMF_T + ox) * CO + cg * 8) = f32_to_bf8(r);
+    }
+    if constexpr (FULL) {
+        __syncthreads();
+        // ---- phase 3: stem[2] on this wave's 16 pixels.  B operand: lane (pixel lr, k-group g) holds y1[px][32 ks + 8 g .. + 7];
+        // A operand: W2 rows 16 ob + lr (output channels), the same k range, straight from the [96][96] bf16 weights (18 KB, L1 / L2 hits);
+        // D: lane holds output channels 16 ob + 4 g .. + 3 of pixel lr.
+        const int lr = lane & 15, g = lane >> 4;
+        char* yrow = y1 + (wave * 16 + lr) * STEMF_PS;
+        bf16x8 yb[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) yb[ks] = *(const bf16x8*)(yrow + ks * 64 + g * 16);
+        const bf16* w2l = w2 + lr * CO + g * 8;
+        bf16x8 wb[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) wb[0][ks] = *(const bf16x8*)(w2l + ks * 32);
+#pragma unroll
+        for (int ob = 0; ob < 6; ++ob) {
+            if (ob + 1 < 6) {
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) wb[(ob + 1) & 1][ks] = *(const bf16x8*)(w2l + (ob + 1) * 16 * CO + ks * 32);
+            }
+            // same arithmetic as the GEMM route (gemm_kernel<3, 32>: three K = 32 MFMAs from zero, then + bias, GELU, one rounding):
+            // the fused result is bit-identical to it
+            const f32x4 bq = *(const f32x4*)(b2 + ob * 16 + g * 4);
+            f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ob & 1][ks], yb[ks], a2, 0, 0, 0);
+            f32x4 gl;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) gl[jj] = gelu_erf(a2[jj] + bq[jj]);
+            *(bf16x4*)(yrow + (ob * 16 + g * 4) * 2) = f32_to_bf4(gl);   // in place: this wave read its 16 rows above
+        }
+        // whole pixels out: chunk c = 16-B piece (c % 12) of pixel 16 wave + c / 12; a tile row of 8 pixels is 1536 B contiguous
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = i * 64 + lane, pxl = wave * 16 + c / 12, part = c % 12;
+            const int oy = pxl / STEMF_T, ox = pxl - oy * STEMF_T;
+            const u32x4 v = *(const u32x4*)(y1 + pxl * STEMF_PS + part * 16);
+            *(u32x4*)(out + (((size_t)b * H2 + ty * STEMF_T + oy) * H2 + tx * STEMF_T + ox) * CO + part * 8) = v;
+        }
+        __syncthreads();                                          // the next tile's phase 0 rewrites the buffer
     }
     }   // tiles of this workgroup
 }
 
 // img [B,3,R,R] (dtype) -> out [B,R/4,R/4,96] bf16 = gelu(dw3x3s2(gelu(conv3x3s2(img) + b0)) + b1);  R % 64 == 0
+// w2 (bf16 [96][96], as the GEMM packs 1x1 weights) / b2 (fp32 [96]) != NULL: stem[2] too - out = gelu(conv1x1(.) + b2)
 extern "C" int fvhd_launch_stem_fused(hipStream_t st, const void* img, int dtype, void* out, const float* w0, const float* b0,
-                                      const float* w1, const float* b1, int B, int R)
+                                      const float* w1, const float* b1, const void* w2, const float* b2, int B, int R)
 {
+    if ((w2 == nullptr) != (b2 == nullptr)) return (int)hipErrorInvalidValue;
+    const bool full = w2 != nullptr;
     if (R % 64) return (int)hipErrorInvalidValue;
     const int txy = R / 4 / STEMF_T;
     const size_t shmem = 6 * 64 * 16 + 9 * 96 * 4 + STEMF_IB + (size_t)STEMF_NP * STEMF_PS;
@@ -332,24 +388,27 @@ extern "C" int fvhd_launch_stem_fused(hipStream_t st, const void* img, int dtype
     constexpr int STEMF_TPW = 4;
     const long G = ntiles >= 4 * 512 * STEMF_TPW ? (ntiles + STEMF_TPW - 1) / STEMF_TPW : ntiles;
     dim3 grid((unsigned)G), block(256);
-    static bool attr_set[64][3];
+    static bool attr_set[64][6];
     int dev = 0;
     (void)hipGetDevice(&dev);
-#define STEMF_LAUNCH(TT, IDX)                                                                                                  \
+#define STEMF_LAUNCH_(TT, FF, IDX)                                                                                             \
     do {                                                                                                                       \
         if (!attr_set[dev & 63][IDX]) {                                                                                        \
-            hipError_t e = hipFuncSetAttribute((const void*)stem_fused_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            hipError_t e = hipFuncSetAttribute((const void*)stem_fused_kernel<TT, FF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                (int)shmem);                                                                    \
             if (e != hipSuccess) return (int)e;                                                                                \
             attr_set[dev & 63][IDX] = true;                                                                                    \
         }                                                                                                                      \
-        hipLaunchKernelGGL(stem_fused_kernel<TT>, grid, block, shmem, st, (const TT*)img, (bf16*)out, w0, b0, w1, b1, B, R, (int)ntiles); \
+        hipLaunchKernelGGL((stem_fused_kernel<TT, FF>), grid, block, shmem, st, (const TT*)img, (bf16*)out, w0, b0, w1, b1,    \
+                           (const bf16*)w2, b2, B, R, (int)ntiles);                                                            \
     } while (0)
+#define STEMF_LAUNCH(TT, IDX) do { if (full) STEMF_LAUNCH_(TT, true, 2 * IDX + 1); else STEMF_LAUNCH_(TT, false, 2 * IDX); } while (0)
     if (dtype == FVHD_F32) STEMF_LAUNCH(float, 0);
     else if (dtype == FVHD_F16) STEMF_LAUNCH(_Float16, 1);
     else if (dtype == FVHD_BF16) STEMF_LAUNCH(bf16, 2);
     else return (int)hipErrorInvalidValue;
 #undef STEMF_LAUNCH
+#undef STEMF_LAUNCH_
     return (int)hipGetLastError();
 }
 

@@ -522,14 +522,29 @@ def test_stem_fused_equals_two_kernels(dtype, B, R):
     one = torch.full_like(two, 7.0)
     _lib.check(lib.fvhd_op_stem_conv(_stream(), _p(imd), _lib.dtype_code(dtype), _p(mid), _p(w0d), _p(b0d), B, R), "stem conv")
     _lib.check(lib.fvhd_op_dwconv(_stream(), _p(mid), _p(two), _p(w1d), _p(b1d), B, R // 2, R // 2, 96, 3, 2, 1, 1), "stem dw")
-    _lib.check(lib.fvhd_op_stem_fused(_stream(), _p(imd), _lib.dtype_code(dtype), _p(one), _p(w0d), _p(b0d), _p(w1d), _p(b1d), B, R),
+    _lib.check(lib.fvhd_op_stem_fused(_stream(), _p(imd), _lib.dtype_code(dtype), _p(one), _p(w0d), _p(b0d), _p(w1d), _p(b1d), None, None, B, R),
                "stem fused")
     torch.cuda.synchronize()
     assert torch.equal(one, two), f"fused stem differs from the two-kernel path: {(one.float() - two.float()).abs().max().item()}"
+    # ... and the WHOLE convolutional_stem in one launch (round 4): stem[2] = 1x1 conv 96 -> 96 + bias + GELU (mci.py:587-598) on the tile
+    # while it is still in LDS - bit-identical to the GEMM kernel on the two-kernel result, and within tolerance of the three fp32 modules
+    w2, b2 = _bf(_rand(96, 96, seed=5, scale=96 ** -0.5)), _rand(96, seed=6, scale=0.1)
+    w2d, b2d = w2.to(DEV), b2.to(DEV)
+    three = torch.empty_like(two)
+    _lib.check(lib.fvhd_op_gemm(_stream(), _p(two), _p(w2d), _p(b2d), None, None, _p(three), B * (R // 4) ** 2, 96, 96, _lib.EPI_BIAS_GELU, _lib.BF16), "stem[2] gemm")
+    full = torch.full_like(two, 7.0)
+    _lib.check(lib.fvhd_op_stem_fused(_stream(), _p(imd), _lib.dtype_code(dtype), _p(full), _p(w0d), _p(b0d), _p(w1d), _p(b1d), _p(w2d), _p(b2d), B, R),
+               "stem fused, all three")
+    torch.cuda.synchronize()
+    assert torch.equal(full, three), f"fully fused stem differs from fused + GEMM: {(full.float() - three.float()).abs().max().item()}"
+    assert lib.fvhd_op_stem_fused(_stream(), _p(imd), _lib.dtype_code(dtype), _p(full), _p(w0d), _p(b0d), _p(w1d), _p(b1d), _p(w2d), None, B, R) != 0
     y0 = _bf(O.gelu(F.conv2d(_bf(img).float(), _bf(w0).float(), b0, stride=2, padding=1))).float()
     want = O.gelu(F.conv2d(y0, w1, b1, stride=2, padding=1, groups=96))
     # two chained modules: a 1-ulp flip of the bf16 intermediate (0.4 %) times a tap of ~0.4 adds to the single-op budget
     _close(one.permute(0, 3, 1, 2), want, rtol=2e-2, atol_rms=2e-2, what=f"fused stem {dtype} B{B} R{R}")
+    y1 = _bf(want).float()
+    want3 = O.gelu(F.conv2d(y1, w2.float()[:, :, None, None], b2))
+    _close(full.permute(0, 3, 1, 2), want3, rtol=3e-2, atol_rms=3e-2, what=f"fully fused stem {dtype} B{B} R{R}")
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])

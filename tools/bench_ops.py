@@ -79,7 +79,7 @@ def bench_stem(B=32, R=1024):
     out = torch.empty(B, R // 4, R // 4, 96, dtype=torch.bfloat16, device=DEV)
     t0 = timeit(lambda: _lib.check(lib.fvhd_op_stem_conv(stream(), p(img), 2, p(mid), p(w0), p(b0), B, R)))
     t1 = timeit(lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(mid), p(out), p(w1), p(b1), B, R // 2, R // 2, 96, 3, 2, 1, 1)))
-    t2 = timeit(lambda: _lib.check(lib.fvhd_op_stem_fused(stream(), p(img), 2, p(out), p(w0), p(b0), p(w1), p(b1), B, R)))
+    t2 = timeit(lambda: _lib.check(lib.fvhd_op_stem_fused(stream(), p(img), 2, p(out), p(w0), p(b0), p(w1), p(b1), p(None), p(None), B, R)))
     by = 2.0 * (img.numel() + out.numel())
     print(f"stem[0] {t0*1e6:8.1f} us + stem[1] {t1*1e6:8.1f} us = {(t0+t1)*1e6:8.1f} us;  fused {t2*1e6:8.1f} us ({by/t2/1e9:6.1f} GB/s algorithmic)")
 
@@ -173,7 +173,8 @@ def bench_gemm(B=32):
               ("llm qkv", 2304, 1152, 896, 1), ("llm o_proj", 2304, 896, 896, 4), ("llm gate_up", 2304, 9728, 896, 5), ("llm down", 2304, 896, 4864, 4)]
     raw = _knobs()
     names = ('v1 only (128x128, register prefetch)', 'default dispatch', '256x128 LDS-DMA ring wherever legal', '256x256 tile / 2-stage LDS-DMA wherever legal',
-             '256x256 ping-pong (two wave groups one phase apart) wherever legal', '256x128 / 4 waves / BK 32 / two workgroups per CU wherever legal')
+             '256x256 ping-pong (two wave groups one phase apart) wherever legal', '256x128 / 4 waves / BK 32 / two workgroups per CU wherever legal',
+             '256x256 / 8 waves / BK 32 / 4-stage ring wherever legal (256x128 / 6 stages otherwise)', '256x128 / 8 waves / BK 32 / 6-stage ring wherever legal')
     variants = tuple(int(v) for v in os.environ.get("BENCH_GEMM_VARIANTS", "0,2,3,4,5,1").split(","))
     for v2 in variants:
       raw.fvhd_debug_set_gemm_v2(v2)
@@ -191,7 +192,7 @@ def bench_gemm(B=32):
         bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
         res = torch.randn(M, N).to(DEV, torch.bfloat16)
         outs = []
-        for v2 in (0, 2, 3, 4, 5):
+        for v2 in (0, 2, 3, 4, 5, 6, 7):
             raw.fvhd_debug_set_gemm_v2(v2)
             out = res.clone() if epi != 5 else torch.zeros(M, N // 2, device=DEV, dtype=torch.bfloat16)
             _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(res), p(out), M, N, K, epi, 2))
@@ -199,7 +200,8 @@ def bench_gemm(B=32):
             outs.append(out.float())
         print(f"gemm {name}: v1 vs 256x128 equal {bool(torch.equal(outs[0], outs[1]))}, v1 vs 256x256 equal {bool(torch.equal(outs[0], outs[2]))}, "
               f"v1 vs ping-pong equal {bool(torch.equal(outs[0], outs[3]))} (max diff {float((outs[0] - outs[3]).abs().max()):.3g}), "
-              f"v1 vs two-workgroup BK 32 equal {bool(torch.equal(outs[0], outs[4]))} (max diff {float((outs[0] - outs[4]).abs().max()):.3g})")
+              f"v1 vs two-workgroup BK 32 equal {bool(torch.equal(outs[0], outs[4]))} (max diff {float((outs[0] - outs[4]).abs().max()):.3g}), "
+              f"v1 vs BK 32 rings equal {bool(torch.equal(outs[0], outs[5]))} / {bool(torch.equal(outs[0], outs[6]))}")
     raw.fvhd_debug_set_gemm_v2(1)
 
 

@@ -31,6 +31,18 @@ extra)      # the other BASELINE configs: TTFT at the 7B width, 1536^2 with bf16
     timeout 400 python bench.py --res 1536 --batch 16 --no-cpu-baseline --no-ttft > ${O}_bench_1536.json 2>/dev/null; echo "1536 rc=$?"; cut -c1-300 ${O}_bench_1536.json
     timeout 400 python bench.py --res 1536 --batch 16 --attn-fp8 --no-cpu-baseline --no-ttft > ${O}_bench_1536_fp8.json 2>/dev/null; echo "1536 fp8 rc=$?"; cut -c1-300 ${O}_bench_1536_fp8.json
     ;;
+stem)       # the fully fused stem: op + step tests, A/B against the round-3 path (FVHD_FUSED_STEM=1) in the whole step
+    timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_steps.py -m gpu -x -q -k "stem or steps" > ${O}_stem_pytest.log 2>&1; echo "pytest rc=$?"; tail -2 ${O}_stem_pytest.log
+    for v in 1 2; do
+        FVHD_FUSED_STEM=$v timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_stem$v.json 2>/dev/null; python - <<PY
+import json
+d=json.load(open("${O}_bench_stem$v.json")); print("FVHD_FUSED_STEM=$v", d["ms_per_step"], d["value"], d["kernels"]["stem"], d["conv_stage"]["frac"])
+PY
+    done
+    ;;
+gemm)       # GEMM tile / ring variants through the debug library's knobs (tools/bench_ops.py gemm)
+    FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so BENCH_GEMM_VARIANTS=${GEMM_VARIANTS:-3,6,7,1} timeout 600 python tools/bench_ops.py gemm 2>&1 | grep -v Warning | tee ${O}_gemm_variants.log
+    ;;
 rest)       # the GPU tests a -x run did not reach + one named file
     timeout 900 python -m pytest ${REST_TESTS:-tests/test_qwen2_prefill.py tests/test_splice.py tests/test_preprocess.py} -m gpu -x -q > ${O}_pytest_rest.log 2>&1; echo "pytest rest rc=$?"; tail -3 ${O}_pytest_rest.log
     ;;

@@ -136,7 +136,7 @@ def stem():
     w0, b0 = (torch.randn(27, 96) * 0.3).to(DEV), (torch.randn(96) * 0.1).to(DEV)
     w1, b1 = (torch.randn(9, 96) * 0.3).to(DEV), (torch.randn(96) * 0.1).to(DEV)
     out = torch.empty(B, R // 4, R // 4, 96, dtype=torch.bfloat16, device=DEV)
-    return (lambda: _lib.check(lib.fvhd_op_stem_fused(stream(), p(img), 2, p(out), p(w0), p(b0), p(w1), p(b1), B, R))), 2.0 * B * (R // 2) ** 2 * 96 * 27, (img, w0, b0, w1, b1, out)
+    return (lambda: _lib.check(lib.fvhd_op_stem_fused(stream(), p(img), 2, p(out), p(w0), p(b0), p(w1), p(b1), p(None), p(None), B, R))), 2.0 * B * (R // 2) ** 2 * 96 * 27, (img, w0, b0, w1, b1, out)
 
 
 def run(name, seconds=3.0):
