@@ -88,7 +88,9 @@ extern "C" int fvhd_launch_layernorm(hipStream_t st, const void* x, void* y, con
 // ---------------------------------------------------------------------------------------------------
 #define ATT_D 32
 #define ATT_KT 64          // keys per tile
+#ifndef ATT_QW
 #define ATT_QW 2           // 16-query blocks per wave: every K / V^T fragment read from LDS feeds ATT_QW MFMAs
+#endif
 #define ATT_QB (64 * ATT_QW)   // queries per workgroup
 #define ATT_VT_STRIDE 136  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
 

@@ -344,7 +344,15 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
                 : launch_dw_tiled<KK, SS, MM, AA, 32>(st, xi, yo, w, bias, B, H, W, Cin);                 \
         return (int)e;                                                                                    \
     }
-    DW_TILED(3, 1, 1, false) DW_TILED(7, 2, 2, true) DW_TILED(3, 2, 1, true) DW_TILED(3, 1, 2, false)
+    // PatchEmbed's depthwise 7x7 / stride 2 / multiplier 2 + GELU (mci.py:442-451).  Round 4 (profiles/r04_dwdown_cfg.log, B = 32): the
+    // register-prefetch form of rounds 1-3 carried 8 spilled VGPRs in its tap loop at the 256-register limit; without the prefetch (loads
+    // at the top of the tile, the other resident workgroups cover them) 309 -> 292 / 163 -> 149 / 42 -> 38 us at C = 96 / 192 / 768, and
+    // 32-channel slices at 3 waves per SIMD 78 -> 65 us at C = 384.  Same accumulation order: identical bits.
+    if (K == 7 && stride == 2 && mult == 2 && gelu && c32) {
+        if (Cin == 384 || !c64) return (int)launch_dw_tiled<7, 2, 2, true, 32, false, 3, 0>(st, xi, yo, w, bias, B, H, W, Cin);
+        return (int)launch_dw_tiled<7, 2, 2, true, 64, false, 2, 0>(st, xi, yo, w, bias, B, H, W, Cin);
+    }
+    DW_TILED(3, 1, 1, false) DW_TILED(3, 2, 1, true) DW_TILED(3, 1, 2, false)
 #undef DW_TILED
     return (int)e;
 }

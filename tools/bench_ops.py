@@ -217,4 +217,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()

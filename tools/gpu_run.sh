@@ -40,6 +40,22 @@ d=json.load(open("${O}_bench_stem$v.json")); print("FVHD_FUSED_STEM=$v", d["ms_p
 PY
     done
     ;;
+attn)       # attention variants (library builds with another ATT_QW): correctness + sustained time
+    for lib in ${ATTN_LIBS:-base qw4}; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "attention" > ${O}_attn_${lib}_pytest.log 2>&1; tail -1 ${O}_attn_${lib}_pytest.log
+        FVHD_LIB=$L timeout 200 python tools/power_probe.py attn 2>/dev/null | tee -a ${O}_attn_power.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py attn 2>/dev/null | tee -a ${O}_attn_ops.log
+    done
+    ;;
+dwdown)     # PatchEmbed dw7x7/s2 tile variants (library builds with -DFVHD_DWDOWN_CFG=n): correctness + time per launch
+    for lib in ${DW_LIBS:-base dd1 dd2}; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "dwconv" > ${O}_dw_${lib}_pytest.log 2>&1; tail -1 ${O}_dw_${lib}_pytest.log
+        echo "--- $lib" | tee -a ${O}_dwdown.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dwraw 2>/dev/null | grep "S=2" | tee -a ${O}_dwdown.log
+    done
+    ;;
 gemm)       # GEMM tile / ring variants through the debug library's knobs (tools/bench_ops.py gemm)
     FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so BENCH_GEMM_VARIANTS=${GEMM_VARIANTS:-3,6,7,1} timeout 600 python tools/bench_ops.py gemm 2>&1 | grep -v Warning | tee ${O}_gemm_variants.log
     ;;
