@@ -123,28 +123,10 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct GeluSt16 { f16x2 x, u, q; };
 #define FFN_H2(bits) (__builtin_bit_cast(f16x2, (unsigned)(bits) * 0x10001u))
-template <int H> FVHD_DEV void gelu_half16(GeluSt16& g, f32x2 x, f16x2& out)
-{
-    // c_k' = 4 * 16^k * FVHD_GELU5_Ck rounded to f16 (c0' + 1 ulp):  1.5927734375, -4.12109375, 8.703125, -11.7890625, 8.9375, -2.84375
-    if constexpr (H == 0) g.x = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
-    else if constexpr (H == 1) {
-        g.u = __builtin_elementwise_min(g.x * g.x, FFN_H2(0x3a20));          // (3.5 / 4)^2 = 0.765625
-        g.q = __builtin_elementwise_fma(FFN_H2(0xc1b0), g.u, FFN_H2(0x4878));
-    } else if constexpr (H == 2) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0xc9e5));
-    else if constexpr (H == 3) g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0x485a));
-    else if constexpr (H == 4) {
-        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0xc41f));
-        g.q = __builtin_elementwise_fma(g.q, g.u, FFN_H2(0x3e5f));
-    } else {
-        f16x2 phi;
-        asm("v_pk_fma_f16 %0, %1, %2, %3 clamp" : "=v"(phi) : "v"(g.x), "v"(g.q), "v"(FFN_H2(0x3800)));
-        out = g.x * phi;
-    }
-}
-
-// The same ten packed instructions, ONE per call (round 4): the iteration issues stage k of several INDEPENDENT pairs in a slot and
-// stage k + 1 in the next, so that no packed instruction directly follows the one it depends on - hipcc separated every such pair
-// with an s_nop (66 of the 833 instructions of two iterations at C = 384), and the iteration is issue-bound.
+// The ten packed instructions of one pair, ONE per call (round 4): the iteration issues stage k of several INDEPENDENT pairs in a slot
+// and stage k + 1 in the next, so that no packed instruction directly follows the one it depends on - in the half-stage form of round 3
+// hipcc separated every such pair with an s_nop (66 of the 833 instructions of two iterations at C = 384).
+// c_k' = 4 * 16^k * FVHD_GELU5_Ck rounded to f16 (c0' + 1 ulp):  1.5927734375, -4.12109375, 8.703125, -11.7890625, 8.9375, -2.84375
 template <int K> FVHD_DEV void gelu16_stage(GeluSt16& g, f32x2 x, f16x2& out)
 {
     if constexpr (K == 0) g.x = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
@@ -300,7 +282,7 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
                 for (int q = 1; q < 4; ++q)     // bias of values 4q..4q+3 (first used by unit 24*q*NB): read ~2 slots ahead
                     if (m == ((24 * q * NB) / UPS >= 2 ? (24 * q * NB) / UPS - 2 : 0)) bv[q] = *(const f32x4*)(b1_prev + 8 * q + 4 * half);
             }
-            if constexpr (F16 && !(VAR & (2 | 64))) {
+            if constexpr (F16) {
                 // half-precision form: slot m issues stage k = m % 10 of the UPS pairs of group m / 10 (NM / 12 groups of UPS = 48 / KS
                 // pairs: 8 NB pairs per iteration) - one instruction per pair and slot, all of them independent of each other
                 constexpr int NGRP = NM / 12;
@@ -311,7 +293,9 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
                     for (int i = 0; i < UPS; ++i) {
                         const int pr = (m / 10) * UPS + i, gb = pr % NB, r = 2 * (pr / NB);      // pair (values r, r + 1) of block gb
                         const f32x2 sv = {s_in[gb][r], s_in[gb][r + 1]};
-                        gelu16_dispatch(k, gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
+                        if constexpr (VAR & 2) {     // ablation: no GELU math (conversion only)
+                            if (k == 9) gout16[gb][r >> 1] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(sv[0], sv[1]));
+                        } else gelu16_dispatch(k, gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
                         if (k == 9) {
                             f16x8 pt = __builtin_bit_cast(f16x8, p_out[gb][r >> 3]);
                             pt[r & 7] = gout16[gb][r >> 1][0];
@@ -323,27 +307,9 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
             } else
 #pragma unroll
             for (int u = m * UPS / 2; u < (m + 1) * UPS / 2; ++u) {     // unit u = ((pair j, half-stage h), block gb)
-                // f32 form: one pair at a time (register budget at C = 384); f16 form: two pairs in flight with their half-stages
-                // alternating, so that consecutive packed instructions are independent (a dependent pair costs an s_nop each)
-                const int gb = u % NB, jh = u / NB, h = F16 ? (jh % 12) / 2 : jh % 6, r = F16 ? 2 * (2 * (jh / 12) + (jh & 1)) : 2 * (jh / 6);
+                // f32 form (FVHD_FFN_BF16 precision): one pair at a time (register budget at C = 384)
+                const int gb = u % NB, jh = u / NB, h = jh % 6, r = 2 * (jh / 6);
                 f32x2 sv = {s_in[gb][r], s_in[gb][r + 1]};
-                if constexpr (F16) {         // b1 / 4 came in through the accumulator (BPRE)
-                    if (VAR & 2) {
-                        if (h == 5) gout16[gb][r >> 1] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(sv[0], sv[1]));
-                    } else if (h == 0) gelu_half16<0>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
-                    else if (h == 1) gelu_half16<1>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
-                    else if (h == 2) gelu_half16<2>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
-                    else if (h == 3) gelu_half16<3>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
-                    else if (h == 4) gelu_half16<4>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
-                    else gelu_half16<5>(gs16[gb][r >> 1], sv, gout16[gb][r >> 1]);
-                    if (h == 5) {
-                        f16x8 pt = __builtin_bit_cast(f16x8, p_out[gb][r >> 3]);
-                        pt[r & 7] = gout16[gb][r >> 1][0];
-                        pt[(r & 7) + 1] = gout16[gb][r >> 1][1];
-                        p_out[gb][r >> 3] = __builtin_bit_cast(bf16x8, pt);
-                    }
-                    continue;
-                }
                 if (!BPRE && (h == 0 || ((VAR & (2 | 64)) && h == 5))) sv += f32x2{bv[r >> 2][r & 3], bv[r >> 2][(r & 3) + 1]};
                 if (VAR & 2) {               // ablation bit 1: no GELU math
                     if (h == 5) gout[gb][r >> 1] = sv;
@@ -966,12 +932,12 @@ static uint16_t to_f16(float f)       // round-to-nearest-even, subnormals kept,
     return (uint16_t)(sign | bits);
 }
 
-// precision: FVHD_FFN_HALF (0) = the half-precision hidden activation (gelu_half16; the default), FVHD_FFN_BF16 (1) = the f32 GELU with a
+// precision: FVHD_FFN_HALF (0) = the half-precision hidden activation (gelu16_stage; the default), FVHD_FFN_BF16 (1) = the f32 GELU with a
 // bf16 hidden operand (no range limit: for blocks whose fc1 output can exceed the f16 form's 262 016, fvhd_audit_ranges)
 extern "C" int fvhd_ffn_pack_host(int C, const float* fc1, const float* fc2, uint16_t* w1img, uint16_t* w2img, int precision)
 {
     if (!fvhd_ffn_fused_supported(C) || precision < 0 || precision > 1) return 1;
-    // half-precision form (see gelu_half16): W1 carries the factor 1/4 (exact in bf16), W2 is f16(4 W2)
+    // half-precision form (see gelu16_stage): W1 carries the factor 1/4 (exact in bf16), W2 is f16(4 W2)
     const bool f16 = precision == 0;
     const float s1 = f16 ? 0.25f : 1.0f;
     const int HID = 4 * C, NCH = HID / 32, CHE = 32 * C;   // bf16 elements per chunk image

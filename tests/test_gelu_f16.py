@@ -1,4 +1,4 @@
-"""The half-precision GELU of the fused ConvFFN (csrc/ffn_fused.hip: gelu_half16), restated in numpy float16 with the kernel's own
+"""The half-precision GELU of the fused ConvFFN (csrc/ffn_fused.hip: gelu16_stage), restated in numpy float16 with the kernel's own
 coefficient bit patterns (parsed from the source, so the two cannot drift apart), against the exact erf GELU the reference uses
 (nn.GELU() default, mci.py:870): the bounds DESIGN.md / include/fvhd.h / INTEGRATION.md state.  CPU only."""
 import os
@@ -14,7 +14,7 @@ h = np.float16
 
 def _kernel_constants():
     src = open(SRC).read()
-    body = src[src.index("void gelu_half16("):src.index("// 16 B/lane LDS-DMA")]
+    body = src[src.index("void gelu16_stage("):src.index("void gelu16_dispatch(")]
     bits = [int(b, 16) for b in re.findall(r"FFN_H2\(0x([0-9a-fA-F]{4})\)", body)]
     # order of appearance: UMAX, c5, c4, c3, c2, c1, c0, 0.5
     assert len(bits) == 8, bits

@@ -56,6 +56,24 @@ dwdown)     # PatchEmbed dw7x7/s2 tile variants (library builds with -DFVHD_DWDO
         FVHD_LIB=$L timeout 200 python tools/bench_ops.py dwraw 2>/dev/null | grep "S=2" | tee -a ${O}_dwdown.log
     done
     ;;
+calib)      # FETCH_SIZE calibration for the access widths of this library (tools/ubench/fetch_calib.hip)
+    hipcc --offload-arch=gfx950 -O3 tools/ubench/fetch_calib.hip -o /tmp/fetch_calib 2>/dev/null
+    (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/fc -o fc -- /tmp/fetch_calib) > ${O}_fetch_calib_run.log 2>&1
+    python - <<PY | tee ${O}_fetch_calib.log
+import csv, glob, collections
+rows = collections.defaultdict(list)
+for f in glob.glob("/tmp/fc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") == "FETCH_SIZE":
+            rows[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+known = {"read16": 256 * 2**20, "read2": 256 * 2**20, "read2r": 21 * 3 * 1024 * 1024 * 2}
+for k, v in sorted(rows.items()):
+    name = next((n for n in known if k.startswith(n)), None)
+    if name is None: continue
+    kib = sum(v) / len(v)
+    print(f"{k:10s} dispatches {len(v)}  FETCH_SIZE {kib * 1024 / 1e6:9.1f} MB per dispatch  bytes of the buffer read once {known[name] / 1e6:9.1f} MB  ratio {kib * 1024 / known[name]:.3f}")
+PY
+    ;;
 gemm)       # GEMM tile / ring variants through the debug library's knobs (tools/bench_ops.py gemm)
     FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so BENCH_GEMM_VARIANTS=${GEMM_VARIANTS:-3,6,7,1} timeout 600 python tools/bench_ops.py gemm 2>&1 | grep -v Warning | tee ${O}_gemm_variants.log
     ;;
