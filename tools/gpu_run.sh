@@ -58,20 +58,21 @@ dwdown)     # PatchEmbed dw7x7/s2 tile variants (library builds with -DFVHD_DWDO
     ;;
 calib)      # FETCH_SIZE calibration for the access widths of this library (tools/ubench/fetch_calib.hip)
     hipcc --offload-arch=gfx950 -O3 tools/ubench/fetch_calib.hip -o /tmp/fetch_calib 2>/dev/null
-    (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/fc -o fc -- /tmp/fetch_calib) > ${O}_fetch_calib_run.log 2>&1
+    (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d /tmp/fc -o fc -- /tmp/fetch_calib) > ${O}_fetch_calib_run.log 2>&1
     python - <<PY | tee ${O}_fetch_calib.log
 import csv, glob, collections
 rows = collections.defaultdict(list)
 for f in glob.glob("/tmp/fc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") == "FETCH_SIZE":
-            rows[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        rows[(r["Kernel_Name"].split("(")[0], r.get("Counter_Name"))].append(float(r["Counter_Value"]))
 known = {"read16": 256 * 2**20, "read2": 256 * 2**20, "read2r": 21 * 3 * 1024 * 1024 * 2}
-for k, v in sorted(rows.items()):
-    name = next((n for n in known if k.startswith(n)), None)
-    if name is None: continue
-    kib = sum(v) / len(v)
-    print(f"{k:10s} dispatches {len(v)}  FETCH_SIZE {kib * 1024 / 1e6:9.1f} MB per dispatch  bytes of the buffer read once {known[name] / 1e6:9.1f} MB  ratio {kib * 1024 / known[name]:.3f}")
+for (k, cn), v in sorted(rows.items()):
+    if k not in known: continue
+    avg = sum(v) / len(v)
+    if cn == "FETCH_SIZE":
+        print(f"{k:8s} dispatches {len(v)}  FETCH_SIZE {avg * 1024 / 1e6:9.1f} MB per dispatch  bytes of the buffer read once {known[k] / 1e6:9.1f} MB  ratio {avg * 1024 / known[k]:.3f}")
+    else:
+        print(f"{k:8s} dispatches {len(v)}  {cn} {avg:.4g} requests per dispatch = {known[k] / max(avg, 1):.1f} B of the buffer per request")
 PY
     ;;
 gemm)       # GEMM tile / ring variants through the debug library's knobs (tools/bench_ops.py gemm)
@@ -79,6 +80,13 @@ gemm)       # GEMM tile / ring variants through the debug library's knobs (tools
     ;;
 rest)       # the GPU tests a -x run did not reach + one named file
     timeout 900 python -m pytest ${REST_TESTS:-tests/test_qwen2_prefill.py tests/test_splice.py tests/test_preprocess.py} -m gpu -x -q > ${O}_pytest_rest.log 2>&1; echo "pytest rest rc=$?"; tail -3 ${O}_pytest_rest.log
+    ;;
+final)      # evidence of the final binary: bench line, small batches, PMC passes + kernel trace
+    timeout 600 python bench.py > ${O}_final_bench.json 2> ${O}_final_bench.err; echo "bench rc=$?"; cut -c1-300 ${O}_final_bench.json
+    timeout 300 python bench.py --batch 8 --no-cpu-baseline --no-ttft > ${O}_bench_b8.json 2>/dev/null; cut -c1-200 ${O}_bench_b8.json
+    timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-ttft > ${O}_bench_b1.json 2>/dev/null; cut -c1-200 ${O}_bench_b1.json
+    timeout 300 python tools/power_probe.py ffn384 ffn192 ffn96 stem attn 2>/dev/null | tee ${O}_final_power.log
+    bash tools/run_pmc.sh ${TAG}
     ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}

@@ -6,7 +6,10 @@
 Kernels are grouped by class (the classes of `fvhd_profile_read` / bench.py's `kernels` table, plus the channel count for the
 fused ConvFFN and the depthwise kernels) with a regular expression on the demangled or mangled name, NOT by exact instantiation,
 so a re-tuned template parameter does not orphan the evidence ("What's weak" 7).
-HBM bytes: read = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md "HBM"), write = WRITE_SIZE x 1024.
+HBM bytes: read = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md "HBM"; calibrated here with
+tools/ubench/fetch_calib.hip, profiles/r04_fetch_calib.log: ratio 0.500 for 16-B AND for lane-linear 2-B loads) - EXCEPT the stem,
+whose 70-B runs of 2-byte NCHW loads go out as genuine 64-B requests (33 B of the buffer per request in the same calibration): factor 1
+there (round 3 doubled it: "594 MB read for a 201-MB image" was 297 MB) -, write = WRITE_SIZE x 1024.
 MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE-derived cycles of the dispatch) when GRBM_GUI_ACTIVE is present
 (the counter is summed over the 8 XCD instances: / 8), else / (1024 x duration x 2.0 GHz)."""
 import glob
@@ -45,6 +48,9 @@ CLASSES = [  # (class, regex on kernel name); first match wins
 ]
 
 
+READ_FACTOR = {"stem": 1.0}          # FETCH_SIZE -> bytes, per class (default 2: wide / lane-linear loads); see the module docstring
+
+
 def classify(name):
     for cls, rx in CLASSES:
         if re.search(rx, name):
@@ -80,10 +86,11 @@ def main():
     # the workload the passes were taken on (tools/run_pmc.sh runs `bench.py` with its defaults): bench.py attaches these counters to a
     # run only when its own workload is the same
     out["_meta"] = json.loads(os.environ.get("FVHD_PMC_META", '{"res": 1024, "batch": 32, "hidden": 896}'))
+    out["_meta"]["read_factor"] = dict(READ_FACTOR, default=2.0)
     json_path = os.path.join("profiles", f"{tag}_pmc_summary.json")
     json.dump(out, open(json_path, "w"), indent=1, sort_keys=True)
     print(f"# PMC summary {tag} (rocprofv3 --pmc, one pass per counter group, B = 32 @1024^2; tools/run_pmc.sh + tools/pmc_summary.py)\n")
-    print("Per kernel class, per dispatch.  HBM read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; MFMA busy = "
+    print("Per kernel class, per dispatch.  HBM read = 2 x FETCH_SIZE KiB (gfx950 correction; 1 x for the stem's 64-B gather requests, calibrated), write = WRITE_SIZE KiB; MFMA busy = "
           "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x dispatch cycles), dispatch cycles from GRBM_GUI_ACTIVE when collected (else 2.0 GHz x duration).\n")
     print("| class | dispatches | avg us (trace) | HBM read MB | HBM write MB | HBM GB/s | MFMA busy % | clock GHz | LDS bank-conflict % | wave-cycles: active / issue-stall / waitcnt % |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---|")
@@ -93,7 +100,7 @@ def main():
             continue
         g = lambda k: c[k]["per_dispatch"] if k in c else None
         us = c["_trace"]["avg_us"] if "_trace" in c else next(iter(c.values()))["avg_us"]
-        rd = 2 * g("FETCH_SIZE") * 1024 / 1e6 if g("FETCH_SIZE") is not None else None
+        rd = READ_FACTOR.get(cls, 2.0) * g("FETCH_SIZE") * 1024 / 1e6 if g("FETCH_SIZE") is not None else None
         wr = g("WRITE_SIZE") * 1024 / 1e6 if g("WRITE_SIZE") is not None else None
         gbs = (rd + wr) / us * 1e3 if rd is not None and wr is not None else None      # MB / us = TB/s
         gui = g("GRBM_GUI_ACTIVE")                                                         # summed over the 8 XCD instances

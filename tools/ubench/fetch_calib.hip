@@ -19,14 +19,14 @@ __global__ void read16(const uint4* __restrict__ p, size_t n16, unsigned* out)
         const uint4 v = p[i];
         acc ^= v.x ^ v.y ^ v.z ^ v.w;
     }
-    if (acc == 0x12345678u) out[0] = acc;
+    atomicXor(out, acc);
 }
 
 __global__ void read2(const unsigned short* __restrict__ p, size_t n2, unsigned* out)
 {
     unsigned acc = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) acc ^= p[i];
-    if (acc == 0x12345678u) out[0] = acc;
+    atomicXor(out, acc);
 }
 
 // images [B][3][R][R] of 2-byte elements; one workgroup per (b, tile of 32 x 32 pixels): reads the 3 x 35 x 35 window under the tile
@@ -45,7 +45,7 @@ __global__ void read2r(const unsigned short* __restrict__ img, int B, int R, uns
         ix = ix < 0 ? 0 : ix >= R ? R - 1 : ix;
         acc ^= ib[((size_t)ci * R + iy) * R + ix];
     }
-    if (acc == 0x12345678u) out[0] = acc;
+    atomicXor(out, acc);
 }
 
 int main()
