@@ -347,14 +347,19 @@ FVHD_DEV void ffn_iter(const bf16x8 (&afr)[NB][C / 16], f32x16 (&o)[NB][C / 32],
 }
 
 // chunk id of a 32-row tile (= row * CPR + 16-B chunk in the row; the tile is contiguous in HBM, so id*16 is also its byte
-// offset) -> LDS byte offset of the transposing stage.  The XOR key (id >> SH) & SWZ equals (3*row + const) mod 2^SH for
-// the rows of one fragment read (CPR = 3 * 2^SH), a bijection on row mod 2^SH: the 16 lanes of a ds_read_b128 group land
-// in 16 different 16-B slots; it only touches the low SH bits, so aligned groups of 64 chunks (the 1-KiB pieces of an
-// LDS-DMA) map onto themselves and the map is an involution (used for the DMA's source-side swizzle).
+// offset) -> LDS byte offset of the transposing stage: a bijection of the tile's chunk ids (XOR of low id bits with higher ones), the
+// same on the writing (lane-linear ids) and the reading side (row li, chunk 2 ks + half).  A fragment ds_read_b128 is served in 16-lane
+// groups (rows {0-3, 12-15, 20-27} / the rest), conflict-free iff their 16 slots differ modulo 16:
+//   C = 384 (CPR 48 = 3 * 16): id mod 16 is the same for every row; key = bits 4-7 of id = (3 row + const) mod 16 - 16 different slots.
+//   C = 192 (CPR 24): round 2-3 used key = bits 3-5 -> low 3 bits only: rows r and r + 8 (24 r = 8 * 3 r) collided, 2-way (PMC: 8.4 %
+//       of the LDS cycles); bit 6 of id (= floor(0.375 row): differs inside every colliding pair of a group) now goes into bit 3.
+//   C = 96 (CPR 12): the old key (bits 2-3 into bits 0-1) only moved entropy that bits 2-3 already carried: 4 slots per group, 4-way
+//       (PMC: 28 %); bits 4-5 of id (= floor(0.75 row)) into bits 0-1 give 16 different slots (checked exhaustively on the host).
 template <int C> FVHD_DEV int ffn_slot_of(int id)
 {
-    constexpr int SH = C == 384 ? 4 : C == 192 ? 3 : 2, SWZ = (1 << SH) - 1;
-    return (id ^ ((id >> SH) & SWZ)) << 4;
+    if constexpr (C == 384) return (id ^ ((id >> 4) & 15)) << 4;
+    else if constexpr (C == 192) return (id ^ (((id >> 3) & 7) ^ (((id >> 6) & 1) << 3))) << 4;
+    else return (id ^ ((id >> 4) & 3)) << 4;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
