@@ -210,7 +210,9 @@ FVHD_DEV void glds_piece(unsigned voff, const void* sbase, unsigned m0v)
 
 // BKT = 32 (debug-build experiment, knob 5): K tiles of 32 in a 3-stage ring = 72 KB at BN = 128, so that TWO 4-wave workgroups share a CU
 // and one's prologue / epilogue runs behind the other's MFMAs; pieces are then 16 rows x 64 B.
-template <int EPI, int ODT, int NWV, int BN = 128, int BKT = 64>
+// ABL (debug library only, knobs 8 / 9; wrong results, timing): 1 = no LDS-DMA (the K loop runs on stale LDS contents), 2 = no fragment
+// reads and no MFMAs either side of the DMA (the DMA stream + barriers alone)
+template <int EPI, int ODT, int NWV, int BN = 128, int BKT = 64, int ABL = 0>
 __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gemm256_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ ls, const bf16* resid, void* out, int M, int N, int K, int tiles_n, int nwg)
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
     const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * RPP * PW) * K);  // W pieces PW wave ..
     const unsigned lds0 = lds_addr(lds2);
     auto issue = [&](int kt) {
+        if constexpr (ABL == 1) return;
         const unsigned st = lds0 + (kt % RS) * STAGE;
         const size_t ko = (size_t)kt * BK * 2;
 #pragma unroll
@@ -280,6 +283,11 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
         if (kt + RS - 1 < nk) issue(kt + RS - 1);     // into the stage tile kt - 1 occupied
         const char* ldsA = lds2 + (kt % RS) * STAGE;
         const char* ldsW = ldsA + BM * BK * 2;
+        if constexpr (ABL == 2) continue;
+        // (Round 4 measured the fragments of both k-steps read up front / double-buffered across the k-steps - 234 registers, all 24
+        // ds_read_b128 ahead of the 64 MFMAs: no change, qkv 0.879 vs 0.892 ms per step - and the ablations of profiles/r04_gemm_ablations.log:
+        // without the LDS-DMA the stage-3 qkv launch takes 142 us, with ONLY the DMA, the barriers and the epilogue stores 112 us, both
+        // together 172 us, for 54 us of MFMA time: the DMA round trip per K tile and the un-overlapped stores bound it, not the reads.)
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 af[MF], wf[NF];
@@ -417,7 +425,7 @@ extern "C" void fvhd_debug_set_gemm_v2(int on) { g_gemm_v2 = on; }
 static constexpr int g_gemm_v2 = 1;
 #endif
 
-template <int EPI, int ODT, int NWV, int BN = 128, int BKT = 64>
+template <int EPI, int ODT, int NWV, int BN = 128, int BKT = 64, int ABL = 0>
 static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
                                  const bf16* resid, void* out, int M, int N, int K)
 {
@@ -425,13 +433,13 @@ static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV, BN, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<BN, BKT, NWV>::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, ODT, NWV, BN, BKT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, G2Cfg<BN, BKT, NWV>::LDS);
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = true;
     }
     const int tiles_m = M / 256, tiles_n = N / BN, nwg = tiles_m * tiles_n;
     constexpr int LDSB = G2Cfg<BN, BKT, NWV>::LDS;
-    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN, BKT>), dim3(nwg), dim3(64 * NWV), LDSB, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN, BKT, ABL>), dim3(nwg), dim3(64 * NWV), LDSB, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
     return hipGetLastError();
 }
 
@@ -600,6 +608,12 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
         const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
 #ifdef FVHD_DEBUG_KNOBS
         if (g_gemm_v2 == 5) return (int)dispatch_gemm256_2wg(st, a, w, bias, ls, r, out, M, N, K, epi);
+        if ((g_gemm_v2 == 8 || g_gemm_v2 == 9) && t256 > 0 && (epi == EPI_NONE || epi == EPI_BIAS_GELU)) {     // ablations of the 256 x 256 kernel
+            if (g_gemm_v2 == 8) return (int)(epi == EPI_NONE ? launch_gemm256<EPI_NONE, FVHD_BF16, 8, 256, 64, 1>(st, a, w, bias, ls, r, out, M, N, K)
+                                                              : launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8, 256, 64, 1>(st, a, w, bias, ls, r, out, M, N, K));
+            return (int)(epi == EPI_NONE ? launch_gemm256<EPI_NONE, FVHD_BF16, 8, 256, 64, 2>(st, a, w, bias, ls, r, out, M, N, K)
+                                         : launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8, 256, 64, 2>(st, a, w, bias, ls, r, out, M, N, K));
+        }
         if (g_gemm_v2 == 6 && t256 > 0) return (int)dispatch_gemm256_bk32<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
         if (g_gemm_v2 == 7 || g_gemm_v2 == 6) return (int)dispatch_gemm256_bk32<128>(st, a, w, bias, ls, r, out, M, N, K, epi);
 #endif

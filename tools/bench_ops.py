@@ -174,7 +174,8 @@ def bench_gemm(B=32):
     raw = _knobs()
     names = ('v1 only (128x128, register prefetch)', 'default dispatch', '256x128 LDS-DMA ring wherever legal', '256x256 tile / 2-stage LDS-DMA wherever legal',
              '256x256 ping-pong (two wave groups one phase apart) wherever legal', '256x128 / 4 waves / BK 32 / two workgroups per CU wherever legal',
-             '256x256 / 8 waves / BK 32 / 4-stage ring wherever legal (256x128 / 6 stages otherwise)', '256x128 / 8 waves / BK 32 / 6-stage ring wherever legal')
+             '256x256 / 8 waves / BK 32 / 4-stage ring wherever legal (256x128 / 6 stages otherwise)', '256x128 / 8 waves / BK 32 / 6-stage ring wherever legal',
+             'ABLATION 256x256: no LDS-DMA (stale operands, wrong results)', 'ABLATION 256x256: DMA + barriers only (no fragment reads, no MFMAs)')
     variants = tuple(int(v) for v in os.environ.get("BENCH_GEMM_VARIANTS", "0,2,3,4,5,1").split(","))
     for v2 in variants:
       raw.fvhd_debug_set_gemm_v2(v2)

@@ -78,6 +78,16 @@ PY
 gemm)       # GEMM tile / ring variants through the debug library's knobs (tools/bench_ops.py gemm)
     FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so BENCH_GEMM_VARIANTS=${GEMM_VARIANTS:-3,6,7,1} timeout 600 python tools/bench_ops.py gemm 2>&1 | grep -v Warning | tee ${O}_gemm_variants.log
     ;;
+gemmlib)    # GEMM source variants as whole libraries (production dispatch): op tests + per-class times in the step
+    for lib in ${GEMM_LIBS:-base fp0}; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "gemm" > ${O}_gemm_${lib}_pytest.log 2>&1; tail -1 ${O}_gemm_${lib}_pytest.log
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_gemm_${lib}.json 2>/dev/null; python - <<PY
+import json
+d=json.load(open("${O}_bench_gemm_${lib}.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("gemm") or k=="projector"})
+PY
+    done
+    ;;
 rest)       # the GPU tests a -x run did not reach + one named file
     timeout 900 python -m pytest ${REST_TESTS:-tests/test_qwen2_prefill.py tests/test_splice.py tests/test_preprocess.py} -m gpu -x -q > ${O}_pytest_rest.log 2>&1; echo "pytest rest rc=$?"; tail -3 ${O}_pytest_rest.log
     ;;
