@@ -154,7 +154,11 @@ template <int K = 0> FVHD_DEV void gelu16_dispatch(int k, GeluSt16& g, f32x2 x, 
 // builtin, 0 with it), which exposes the full LDS latency before every MFMA.  hipcc does not count an asm load, so the
 // consumer side waits explicitly: s_waitcnt vmcnt(0) before the barrier that publishes the images (ffn_wait_dma).
 // M0 is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md 5.7).
+#ifdef FVHD_FFN_ABL_NOWAIT      // ablation (wrong results, timing only): the chunk loop never waits for its weight DMA
+FVHD_DEV void ffn_wait_dma() {}
+#else
 FVHD_DEV void ffn_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 
 // One pipeline iteration t, for the NB 32-row blocks a wave owns:
 //     s_out <- b1(t) + GEMM1(chunk t);   p_out <- GELU(s_in = S(t-1));   O += GEMM2(chunk t-2, p_in = P(t-2)).

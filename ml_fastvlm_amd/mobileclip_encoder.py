@@ -114,13 +114,15 @@ class MobileCLIPVisionTower(nn.Module):
         inv = getattr(args, "mm_vision_batch_invariant", None)
         self.batch_invariant = None if inv is None else bool(inv)
         # precision of the fused ConvFFN's hidden activation (include/fvhd.h "precision of the fused ConvFFN's hidden activation"):
-        # "half" (default; gelu(x)/4 in IEEE half - saturates beyond |fc1 output| = 262 016) or "bf16" (every block on the f32-GELU /
-        # bf16-operand form of the same kernel: no range limit, a few % slower).  Per block: `audit_ranges()` below.
+        # "half" (default; gelu(x)/4 in IEEE half - saturates beyond |fc1 output| = 262 016), "bf16" (every block on the f32-GELU /
+        # bf16-operand form of the same kernel: no range limit, a few % slower) or "auto" (the FIRST batch encoded after a weight load is
+        # also the calibration batch of `audit_ranges()`: one extra eager pass, then only the blocks that need it run the bf16 form).
         prec = getattr(args, "mm_vision_ffn_precision", None) or "half"
-        if prec not in ("half", "bf16"):
-            raise ValueError(f"mm_vision_ffn_precision must be 'half' or 'bf16', got {prec!r}")
+        if prec not in ("half", "bf16", "auto"):
+            raise ValueError(f"mm_vision_ffn_precision must be 'half', 'bf16' or 'auto', got {prec!r}")
         self.ffn_precision = prec
         self._ffn_bf16_steps = set()            # steps an audit moved to the bf16 form (re-applied whenever the weights are re-packed)
+        self._ffn_audited = False               # "auto": has the current weight set seen its calibration batch?
         # expected batch size (sizes the library's workspace up front; it grows geometrically when a larger batch arrives)
         self._batch_hint = max(1, int(getattr(args, "mm_vision_max_batch", 1) or 1))
         self._ctx: Optional[_lib.Context] = None
@@ -163,6 +165,7 @@ class MobileCLIPVisionTower(nn.Module):
     def _mark_dirty(self) -> None:
         self._dirty = True
         self._ffn_bf16_steps = set()            # new weights: an earlier range audit says nothing about them
+        self._ffn_audited = False
 
     def _apply(self, fn, *a, **kw):
         # .to() / .half() / .cuda(): parameter storage (and possibly values, through a dtype cast) changes
@@ -229,6 +232,7 @@ class MobileCLIPVisionTower(nn.Module):
             report.append({"step": i, "kind": kind, "stage": stage, "block": block, "max_abs_fc1": maxes[i],
                            "precision": {-1: "two GEMMs (bf16 hidden tensor in HBM)", 0: "half", 1: "bf16"}[now],
                            "switched": now == _lib.FFN_BF16 and before[i] == _lib.FFN_HALF})
+        self._ffn_audited = True
         if switched:
             import warnings
             hot = [(r["step"], r["max_abs_fc1"]) for r in report if r["switched"]]
@@ -282,9 +286,14 @@ class MobileCLIPVisionTower(nn.Module):
                 self._batch_hint *= 2
             ctx.reserve(self._batch_hint)
 
+    def _auto_audit(self, images: torch.Tensor) -> None:
+        if self.ffn_precision == "auto" and not self._ffn_audited:
+            self.audit_ranges(images)
+
     def _encode(self, images: torch.Tensor) -> torch.Tensor:
         images = self._check_images(images)
         ctx = self._context()
+        self._auto_audit(images)
         self._grow(ctx, images.shape[0])
         out = torch.empty((images.shape[0], ctx.num_tokens, self.hidden_size), device=images.device, dtype=images.dtype)
         ctx.encode(images, out)
@@ -347,6 +356,7 @@ class MobileCLIPVisionTower(nn.Module):
             images = self._check_images(images)
             weights = self._check_projector(projector)
             ctx = self._context()
+            self._auto_audit(images)
             hid = self._bind_projector(ctx, weights)
             self._grow(ctx, images.shape[0])
             out = torch.empty((images.shape[0], ctx.num_tokens, hid), device=images.device, dtype=images.dtype)

@@ -98,3 +98,27 @@ def test_every_block_on_the_bf16_form_by_configuration():
         assert rel <= 1e-2 and cos >= 0.9999, (prec, rel, cos)
     with pytest.raises(ValueError):
         fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_ffn_precision="fp8"))
+
+
+def test_auto_precision_audits_the_first_batch():
+    """mm_vision_ffn_precision='auto': the first batch after a weight load doubles as the calibration batch - the saturating block is
+    found and moved before the first result is produced, later calls do not audit again, new weights do."""
+    sd = _hot_state_dict()
+    x = synth.synthetic_images(2, 256, seed=5)
+    want = O.tower_forward(x, sd)
+    tower = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_batch_invariant=True,
+                                                                          mm_vision_ffn_precision="auto"))
+    tower.vision_tower.model.load_state_dict(sd, strict=True)
+    tower = tower.to(DEV, torch.bfloat16)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        first = tower(x.to(DEV)).float().cpu()
+    assert any("ConvFFN block" in str(w.message) for w in caught)
+    rel, cos = _metrics(first, want)
+    assert rel <= 1.5e-2 and cos >= 0.9998, (rel, cos)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        assert torch.equal(tower(x.to(DEV)).float().cpu(), first)
+    assert not caught, "the audit runs once per weight set"
+    tower.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234, "mild"), strict=True)
+    assert tower._ffn_audited is False
