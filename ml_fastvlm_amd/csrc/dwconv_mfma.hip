@@ -45,6 +45,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int DWM_P = 80;        // pitch (px) of one channel row of the transposed image: (P/2) % 64 == 40 -> the 16 channels of an A read fall on 8 bank groups (2-way = the 512-B minimum)
 constexpr int DWM_RS = 4;        // raw-row ring depth
+#ifndef DWM_ABL                  // timing-only ablations (wrong results; bit 0: no transposing writes, 1: no staging writes, 2: no per-row barrier)
+#define DWM_ABL 0
+#endif
 // NW waves per workgroup = NW adjacent channel groups = 16 NW channels: 4 (64 channels = one 128-B line per pixel; C = 192, 384, ...)
 // or 6 (96 channels: with C = 96 the whole row segment of the strip is contiguous in memory)
 template <int NW> struct DwmCfg {
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
             // own pieces of row r + 1 have landed once at most the RS - 2 later rows' pieces are outstanding (only loads are
             // counted: stores may retire ahead of older loads); own staging writes of the previous iteration retired
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (RS - 2)) : "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(DWM_ABL & 4)) __builtin_amdgcn_s_barrier();
             const int nslot = slot + 1 == RS ? 0 : slot + 1;
             s16x4 a[3][NT];                                     // A operands of the three segments
             u32x4 tv[3], ov[2];
@@ -259,20 +262,20 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                 }
                 if (k == 5) o_store(ov, r - 4);                 // staged in the previous iteration
                 if (k == 8) dma(min(r + RS, r_hi - 1), slot);   // row r's slot: every wave transposed it before this iteration's barrier
-                if (k >= 10 && k < 18) tr_write1(tv, tb ^ 1, 0, k - 10);
-                if (k >= 18 && k < 26) tr_write1(tv, tb ^ 1, 1, k - 18);
+                if (!(DWM_ABL & 1) && k >= 10 && k < 18) tr_write1(tv, tb ^ 1, 0, k - 10);
+                if (!(DWM_ABL & 1) && k >= 18 && k < 26) tr_write1(tv, tb ^ 1, 1, k - 18);
                 if (k == 30) {
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) a[2][tt] = *(const s16x4*)&rd[tb * (16 * P) + 16 * tt + 8];
                 }
-                if (k >= 32 && k < 40) tr_write1(tv, tb ^ 1, 2, k - 32);
+                if (!(DWM_ABL & 1) && k >= 32 && k < 40) tr_write1(tv, tb ^ 1, 2, k - 32);
                 if (k == 62) {
                     // the slot's last update was MFMA 56..59: pin its readers behind the stream position (the compiler does not
                     // know the asm statements are MFMAs and once scheduled the first v_cvt right behind the last MFMA: stale registers)
                     asm volatile("" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
                     stage_cvt(pk, acc[u]);
                 }
-                if (k >= 64 && k < 80) stage_write1(pk, ob, k - 64);
+                if (!(DWM_ABL & 2) && k >= 64 && k < 80) stage_write1(pk, ob, k - 64);
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = nslot;

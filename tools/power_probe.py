@@ -105,8 +105,8 @@ def gemm():
     return (lambda: _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(None), p(None), p(out), M, N, K, 2, 2))), 2.0 * M * N * K, (A, W, bias, out)
 
 
-def dw7():
-    B, H, Cc = 32, 128, 192
+def dw7(Cc=192):
+    B, H = 32, {96: 256, 192: 128, 384: 64}[Cc]
     x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
     y = torch.empty_like(x)
     w = torch.randn(49, Cc, device=DEV)
@@ -149,7 +149,7 @@ def run(name, seconds=3.0):
     elif name in ("attn", "dw3", "stem"):
         fn, flops, keep = {"attn": attn, "dw3": dw3, "stem": stem}[name]()
     else:
-        fn, flops, keep = dw7()
+        fn, flops, keep = dw7(int(name[4:]) if name.startswith("dw7c") else 192)       # dw7, dw7c96, dw7c384
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
