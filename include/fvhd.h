@@ -302,6 +302,20 @@ int fvhd_op_rope(fvhd_stream_t stream, void* qkv, const int64_t* pos, const floa
  * summed in order (deterministic) and rounded once.  N % 128 == 0, K % (64 * splits) == 0. */
 int fvhd_op_gemm_splitk(fvhd_stream_t stream, const void* A, const void* Wt, const void* resid, void* out, float* partial, int M, int N,
                         int K, int splits);
+/* the same, and norm_out = Qwen2RMSNorm(out) with weight norm_w (fp32 [N]) from the reduce kernel's own pass over the finished rows - the
+ * norm the next operation of a decoder layer starts with (transformers Qwen2DecoderLayer.forward: post_attention_layernorm behind o_proj,
+ * input_layernorm of the next layer behind down_proj).  Both outputs are bit-identical to fvhd_op_gemm_splitk followed by fvhd_op_rmsnorm.
+ * norm_out [M, N] bf16 must not alias out. */
+int fvhd_op_gemm_splitk_norm(fvhd_stream_t stream, const void* A, const void* Wt, const void* resid, void* out, float* partial, int M, int N,
+                             int K, int splits, const float* norm_w, void* norm_out, float eps);
+/* the q|k|v projection of a decoder layer as a split-K GEMM whose reduce finishes the projection: qkv = bf16(A . Wt^T + bias) rows
+ * [M, (n_heads + 2 n_kv_heads) * head_dim], then fvhd_op_rope's rotation of the q and k heads and cache copies, in one pass
+ * (bit-identical to the separate steps on the same partial sums).  A [Mp, K] bf16 with Mp >= M rows readable (Mp = M rounded up to 128),
+ * partial: fp32 scratch [splits][Mp][width]; width % 128 == 0, K % (64 * splits) == 0.  Replaces transformers Qwen2Attention.forward's
+ * q_proj / k_proj / v_proj + apply_rotary_pos_emb + DynamicCache.update. */
+int fvhd_op_qkv_splitk_rope(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, float* partial, void* qkv, const int64_t* pos,
+                            const float* table, void* k_cache, void* v_cache, int M, int Mp, int K, int T, int n_heads, int n_kv_heads, int head_dim,
+                            int table_positions, float rope_theta, int splits);
 /* causal grouped-query attention with a key-padding mask: qkv [B*T, (n_heads + 2 n_kv_heads) * head_dim] bf16 ->
  * out [B*T, n_heads * head_dim] bf16; key_valid uint8 [B, T] or NULL; head_dim in {64, 128} */
 int fvhd_op_attention_causal(fvhd_stream_t stream, const void* qkv, void* out, const uint8_t* key_valid, int B, int T, int n_heads,

@@ -79,6 +79,8 @@ def _declare(lib) -> None:
         "fvhd_llm_workspace_generation": (ci, [vp]),
         "fvhd_op_attention_causal": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci]),
         "fvhd_op_gemm_splitk": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci]),
+        "fvhd_op_qkv_splitk_rope": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, ci]),
+        "fvhd_op_gemm_splitk_norm": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, C.c_float]),
     }
     del fp, cl
     for name, (res, args) in sig.items():

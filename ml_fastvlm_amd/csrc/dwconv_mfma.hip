@@ -309,16 +309,27 @@ done:
 
 }  // namespace
 
-// rows per chunk: 32 (38 input rows per 32 output rows - measured best of 16 / 22 / 32 / 43 / 64 at B = 32) while that still fills the
-// chip; smaller chunks for small batches (a workgroup is a serial march down its rows: 12 workgroups per image at stage 3 would
-// leave a B = 8 launch on 96 of 256 CUs); 0 = too few workgroups even at 8 rows -> the VALU kernel (finer tiles) is the better choice
+// rows per chunk: 32 (38 input rows per 32 output rows - measured best of 16 / 22 / 32 / 43 / 64 at B = 32) while that still gives ~one
+// workgroup per CU; smaller chunks for small batches (a workgroup is a serial march down its rows: 12 workgroups per image at stage 3 would
+// leave a B = 8 launch on 96 of 256 CUs) - but not smaller than that needs: at B = 8 (profiles/r04_dw7_small_batch.log) 192-256 workgroups
+// of the larger chunk beat 384-512 of the smaller one (C = 96: 57.9 vs 70.2 us, C = 384: 25.1 vs 28.7, C = 192: 37.0 vs 39.8; the halo rows
+// are 19 % of the work at 32 rows per chunk, 38 % at 16, 75 % at 8).  0 = too few workgroups even at 8 rows -> the VALU kernel (finer tiles)
+// is the better choice (B = 1, C = 96: 18.8 vs 24.4 us)
+#ifdef FVHD_DEBUG_KNOBS
+static int g_dwm_rc = 0;                                     // > 0: rows per chunk forced (tools/bench_ops.py dw7small)
+extern "C" void fvhd_debug_set_dwm_rc(int rc) { g_dwm_rc = rc; }
+#else
+static constexpr int g_dwm_rc = 0;
+#endif
+
 static int dwm_rows_per_chunk(int B, int H, int W, int C)
 {
+    if (g_dwm_rc > 0) return g_dwm_rc;
     const int nw = C % 64 == 0 ? 4 : 6;
     const long long per_row_chunk = (long long)B * (C / (16 * nw)) * ((W + 63) / 64);
-    if (per_row_chunk * ((H + 31) / 32) >= 384) return 32;
-    if (per_row_chunk * ((H + 15) / 16) >= 256) return 16;
-    if (per_row_chunk * ((H + 7) / 8) >= 128) return 8;
+    if (per_row_chunk * ((H + 31) / 32) >= 192) return 32;
+    if (per_row_chunk * ((H + 15) / 16) >= 192) return 16;
+    if (per_row_chunk * ((H + 7) / 8) >= 192) return 8;
     return 0;
 }
 

@@ -550,20 +550,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *(bf16x4*)(out + i) = f32_to_bf4(v);
 }
 
+// The same reduce for rows that are whole hidden states (N = the model width), followed by the RMSNorm the NEXT operation starts with
+// (Qwen2DecoderLayer: x = x + down_proj(...) / x + o_proj(...), then input_layernorm / post_attention_layernorm of x): one wave per row
+// writes out = bf16(resid + sum of the slices) and nout = norm_w * out * rsqrt(mean(out^2) + eps).  Summation order, the rounding of `out`
+// before the statistics and the order of the sum of squares are those of splitk_reduce_kernel followed by rmsnorm_kernel (llm.hip): the
+// two outputs are bit-identical to the two separate launches - one launch and one pass over the row less per decoder layer.
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ part, const bf16* resid, bf16* out, const float* __restrict__ nw,
+                                                                 bf16* __restrict__ nout, int M, int N, int splits, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const size_t mn = (size_t)M * N, ro = (size_t)row * N;
+    float ss = 0.f;
+    for (int c = lane * 8; c < N; c += 512) {
+        f32x4 v0 = *(const f32x4*)(part + ro + c), v1 = *(const f32x4*)(part + ro + c + 4);
+        for (int s = 1; s < splits; ++s) { v0 += *(const f32x4*)(part + s * mn + ro + c); v1 += *(const f32x4*)(part + s * mn + ro + c + 4); }
+        if (resid) { v0 += bf4_to_f32(*(const bf16x4*)(resid + ro + c)); v1 += bf4_to_f32(*(const bf16x4*)(resid + ro + c + 4)); }
+        const bf16x4 b0 = f32_to_bf4(v0), b1 = f32_to_bf4(v1);
+        *(bf16x4*)(out + ro + c) = b0;
+        *(bf16x4*)(out + ro + c + 4) = b1;
+        const f32x4 r0 = bf4_to_f32(b0), r1 = bf4_to_f32(b1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ss = __builtin_fmaf(r0[k], r0[k], ss);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ss = __builtin_fmaf(r1[k], r1[k], ss);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)N + eps);
+    for (int c = lane * 8; c < N; c += 512) {               // the lane re-reads its own stores
+        const f32x4 r0 = bf4_to_f32(*(const bf16x4*)(out + ro + c)), r1 = bf4_to_f32(*(const bf16x4*)(out + ro + c + 4));
+        const f32x4 w0 = *(const f32x4*)(nw + c), w1 = *(const f32x4*)(nw + c + 4);
+        f32x4 o0, o1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o0[k] = r0[k] * rstd * w0[k]; o1[k] = r1[k] * rstd * w1[k]; }
+        *(bf16x4*)(nout + ro + c) = f32_to_bf4(o0);
+        *(bf16x4*)(nout + ro + c + 4) = f32_to_bf4(o1);
+    }
+}
+
 // A [M, K] bf16, Wt [N, K] bf16, resid bf16 [M, N] or null (may alias out), out [M, N] bf16, partial: fp32 scratch [splits][M][N].
-// K % (64 * splits) == 0, N % 128 == 0.
-extern "C" int fvhd_launch_gemm_splitk(hipStream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial,
-                                       int M, int N, int K, int splits)
+// K % (64 * splits) == 0, N % 128 == 0.  norm_w != null (fp32 [N], with norm_out [M, N] bf16, not aliasing out): the RMSNorm of the
+// finished rows as well (splitk_reduce_norm_kernel).
+extern "C" int fvhd_launch_gemm_splitk_norm(hipStream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial,
+                                            int M, int N, int K, int splits, const float* norm_w, void* norm_out, float eps)
 {
     if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || N % 128 || K % (64 * splits) || !partial) return (int)hipErrorInvalidValue;
+    if ((norm_w == nullptr) != (norm_out == nullptr) || (norm_out && norm_out == out)) return (int)hipErrorInvalidValue;
     const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
     hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
                        nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const long mn = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, partial, (const bf16*)resid, (bf16*)out, mn, splits);
+    if (norm_w)
+        hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, partial, (const bf16*)resid, (bf16*)out, norm_w,
+                           (bf16*)norm_out, M, N, splits, eps);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, partial, (const bf16*)resid, (bf16*)out, mn, splits);
     return (int)hipGetLastError();
+}
+
+// only the partials [splits][M][N] (fp32): for a caller with its own reduce (llm.hip: bias + rotary embedding behind the q|k|v projection)
+extern "C" int fvhd_launch_gemm_splitk_partials(hipStream_t st, const void* A, const void* Wt, float* partial, int M, int N, int K, int splits)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || N % 128 || K % (64 * splits) || !partial) return (int)hipErrorInvalidValue;
+    const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
+    hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
+                       nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fvhd_launch_gemm_splitk(hipStream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial,
+                                       int M, int N, int K, int splits)
+{
+    return fvhd_launch_gemm_splitk_norm(st, A, Wt, resid, out, partial, M, N, K, splits, nullptr, nullptr, 0.f);
 }
 
 template <int NF, int BK>

@@ -55,6 +55,40 @@ extern "C" int fvhd_launch_rmsnorm(hipStream_t st, const void* x, void* y, const
 // with (cos_i, sin_i) = table[pos[row]][i]: fp32 [P][HD/2][2], computed on the host like Qwen2RotaryEmbedding.forward (fp32).
 // One thread = 4 consecutive i of one head of one row.  With kcache / vcache != null the rotated k and the v heads are also written
 // to the KV cache [B][nkv][T][HD] (the layout of transformers' DynamicCache layers) for a decode loop to continue from.
+// (cos, sin) of i4 .. i4 + 3 at position p, then the rotation of one (a, b) = (x[i4..], x[i4 + HD/2 ..]) pair of quads - shared by the two kernels below
+FVHD_DEV void rope_rotate(const f32x4 a, const f32x4 b, long p, int i4, const float* __restrict__ table, int HD, int P, float theta, bf16x4& ra, bf16x4& rb)
+{
+    f32x4 cs0, cs1;                                              // (cos, sin) of i4, i4+1 | i4+2, i4+3
+    if (p >= 0 && p < P) {
+        const float* tb = table + ((size_t)p * (HD / 2) + i4) * 2;
+        cs0 = *(const f32x4*)tb;
+        cs1 = *(const f32x4*)(tb + 4);
+    } else {
+        // a position outside the table (a caller continuing a context longer than the table, or a negative id): the phases are
+        // computed here with the table's own formula - inv_freq_i = theta^(-2i / HD), angle = p * inv_freq_i in fp32 - instead of being
+        // clamped to the table's edge (which gave plausible but wrong logits without an error: advisor, round 3)
+        float cs[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float inv = 1.0f / powf(theta, (float)(2 * (i4 + k)) / (float)HD);      // the host's expression for the table rows
+            const float ang = (float)p * inv;
+            cs[2 * k] = cosf(ang);
+            cs[2 * k + 1] = sinf(ang);
+        }
+        cs0 = f32x4{cs[0], cs[1], cs[2], cs[3]};
+        cs1 = f32x4{cs[4], cs[5], cs[6], cs[7]};
+    }
+    const float c[4] = {cs0[0], cs0[2], cs1[0], cs1[2]}, s[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
+    f32x4 oa, ob;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        oa[k] = a[k] * c[k] - b[k] * s[k];
+        ob[k] = b[k] * c[k] + a[k] * s[k];
+    }
+    ra = f32_to_bf4(oa);
+    rb = f32_to_bf4(ob);
+}
+
 __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const long* __restrict__ pos, const float* __restrict__ table,
                                                    bf16* __restrict__ kcache, bf16* __restrict__ vcache, int M, int T, int nh, int nkv, int HD, int P,
                                                    float theta)
@@ -78,39 +112,51 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const
     }
     bf16* xr = qkv + (size_t)row * width + head * HD;
     const long p = pos ? pos[row] : (long)(row % T);
-    f32x4 cs0, cs1;                                              // (cos, sin) of i4, i4+1 | i4+2, i4+3
-    if (p >= 0 && p < P) {
-        const float* tb = table + ((size_t)p * (HD / 2) + i4) * 2;
-        cs0 = *(const f32x4*)tb;
-        cs1 = *(const f32x4*)(tb + 4);
-    } else {
-        // a position outside the table (a caller continuing a context longer than the table, or a negative id): the phases are
-        // computed here with the table's own formula - inv_freq_i = theta^(-2i / HD), angle = p * inv_freq_i in fp32 - instead of being
-        // clamped to the table's edge (which gave plausible but wrong logits without an error: advisor, round 3)
-        float cs[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float inv = 1.0f / powf(theta, (float)(2 * (i4 + k)) / (float)HD);      // the host's expression for the table rows
-            const float ang = (float)p * inv;
-            cs[2 * k] = cosf(ang);
-            cs[2 * k + 1] = sinf(ang);
-        }
-        cs0 = f32x4{cs[0], cs[1], cs[2], cs[3]};
-        cs1 = f32x4{cs[4], cs[5], cs[6], cs[7]};
-    }
     const f32x4 a = bf4_to_f32(*(const bf16x4*)(xr + i4)), b = bf4_to_f32(*(const bf16x4*)(xr + i4 + HD / 2));
-    const float c[4] = {cs0[0], cs0[2], cs1[0], cs1[2]}, s[4] = {cs0[1], cs0[3], cs1[1], cs1[3]};
-    f32x4 oa, ob;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        oa[k] = a[k] * c[k] - b[k] * s[k];
-        ob[k] = b[k] * c[k] + a[k] * s[k];
-    }
-    const bf16x4 ra = f32_to_bf4(oa), rb = f32_to_bf4(ob);
+    bf16x4 ra, rb;
+    rope_rotate(a, b, p, i4, table, HD, P, theta, ra, rb);
     *(bf16x4*)(xr + i4) = ra;
     *(bf16x4*)(xr + i4 + HD / 2) = rb;
     if (kcache && head >= nh) {
         bf16* dst = kcache + (((size_t)(row / T) * nkv + (head - nh)) * T + row % T) * HD;
+        *(bf16x4*)(dst + i4) = ra;
+        *(bf16x4*)(dst + i4 + HD / 2) = rb;
+    }
+}
+
+// The reduce of a split-K q|k|v projection (fvhd_launch_gemm_splitk_partials: fp32 partials [splits][Mp][width]) with everything that
+// follows the projection in Qwen2Attention.forward: + bias, ONE rounding to bf16 (what the projection's own epilogue does), rotary
+// embedding of the q and k heads, the KV-cache copies.  Same thread layout and the same arithmetic as rope_kernel - the result is
+// bit-identical to reduce + bias -> rope_kernel; one launch and one pass over the packed rows less per decoder layer.
+__global__ __launch_bounds__(256) void splitk_bias_rope_kernel(const float* __restrict__ part, int splits, size_t slice, const float* __restrict__ bias,
+                                                               bf16* __restrict__ qkv, const long* __restrict__ pos, const float* __restrict__ table,
+                                                               bf16* __restrict__ kcache, bf16* __restrict__ vcache, int M, int T, int nh, int nkv, int HD,
+                                                               int P, float theta)
+{
+    const int per_head = HD / 8;
+    const int nheads = nh + 2 * nkv;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)M * nheads * per_head;
+    if (idx >= total) return;
+    const int i4 = (int)(idx % per_head) * 4;
+    const int head = (int)((idx / per_head) % nheads);
+    const int row = (int)(idx / ((long)per_head * nheads));
+    const int width = nheads * HD, col = head * HD + i4;
+    const float* pr = part + (size_t)row * width + col;
+    f32x4 a = *(const f32x4*)pr, b = *(const f32x4*)(pr + HD / 2);
+    for (int s = 1; s < splits; ++s) { a += *(const f32x4*)(pr + s * slice); b += *(const f32x4*)(pr + s * slice + HD / 2); }
+    if (bias) { a += *(const f32x4*)(bias + col); b += *(const f32x4*)(bias + col + HD / 2); }
+    bf16x4 ra = f32_to_bf4(a), rb = f32_to_bf4(b);               // the projection's output as the reference holds it (bf16)
+    bf16* xr = qkv + (size_t)row * width + head * HD;
+    if (head < nh + nkv) {
+        const long p = pos ? pos[row] : (long)(row % T);
+        rope_rotate(bf4_to_f32(ra), bf4_to_f32(rb), p, i4, table, HD, P, theta, ra, rb);
+    }
+    *(bf16x4*)(xr + i4) = ra;
+    *(bf16x4*)(xr + i4 + HD / 2) = rb;
+    if (kcache && head >= nh) {
+        bf16* dst = (head < nh + nkv ? kcache + (((size_t)(row / T) * nkv + (head - nh)) * T + row % T) * HD
+                                     : vcache + (((size_t)(row / T) * nkv + (head - nh - nkv)) * T + row % T) * HD);
         *(bf16x4*)(dst + i4) = ra;
         *(bf16x4*)(dst + i4 + HD / 2) = rb;
     }
@@ -124,6 +170,19 @@ extern "C" int fvhd_launch_rope(hipStream_t st, void* qkv, const long* pos, cons
     const long total = (long)M * (nh + nkv + (vcache ? nkv : 0)) * (HD / 8);
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (bf16*)qkv, pos, table, (bf16*)kcache, (bf16*)vcache,
                        M, T, nh, nkv, HD, P, theta);
+    return (int)hipGetLastError();
+}
+
+// partials fp32 [splits][Mp][(nh + 2 nkv) * HD] of the split-K projection (Mp >= M rows per slice) -> qkv rows [M, width] bf16 (+ bias, rotary, caches)
+extern "C" int fvhd_launch_splitk_bias_rope(hipStream_t st, const float* partial, int splits, int Mp, const float* bias, void* qkv, const long* pos,
+                                            const float* table, void* kcache, void* vcache, int M, int T, int nh, int nkv, int HD, int P, float theta)
+{
+    if (M <= 0 || Mp < M || splits < 1 || T <= 0 || nh <= 0 || nkv <= 0 || HD % 8 || P <= 0 || !(theta > 0.f) || (kcache == nullptr) != (vcache == nullptr))
+        return (int)hipErrorInvalidValue;
+    const int width = (nh + 2 * nkv) * HD;
+    const long total = (long)M * (nh + 2 * nkv) * (HD / 8);
+    hipLaunchKernelGGL(splitk_bias_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, splits, (size_t)Mp * width, bias, (bf16*)qkv,
+                       pos, table, (bf16*)kcache, (bf16*)vcache, M, T, nh, nkv, HD, P, theta);
     return (int)hipGetLastError();
 }
 

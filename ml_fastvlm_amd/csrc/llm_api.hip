@@ -15,6 +15,9 @@
 extern "C" {
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_launch_gemm_splitk(hipStream_t, const void*, const void*, const void*, void*, float*, int, int, int, int);
+int fvhd_launch_gemm_splitk_partials(hipStream_t, const void*, const void*, float*, int, int, int, int);
+int fvhd_launch_splitk_bias_rope(hipStream_t, const float*, int, int, const float*, void*, const long*, const float*, void*, void*, int, int, int, int, int, int, float);
+int fvhd_launch_gemm_splitk_norm(hipStream_t, const void*, const void*, const void*, void*, float*, int, int, int, int, const float*, void*, float);
 int fvhd_launch_rmsnorm(hipStream_t, const void*, void*, const float*, int, int, float);
 int fvhd_launch_rope(hipStream_t, void*, const long*, const float*, void*, void*, int, int, int, int, int, int, float);
 int fvhd_launch_llm_attention(hipStream_t, const void*, void*, const unsigned char*, int, int, int, int, int);
@@ -89,7 +92,7 @@ struct fvhd_llm {
     int ws_rows = 0, ws_batch = 0, ws_pos = 0;
     char *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *last = nullptr, *lastn = nullptr;
     float *rope = nullptr, *part = nullptr;
-    int down_splits = 1;
+    int down_splits = 1, o_splits = 2, qkv_splits = 0, fuse_norm = 1;     // FVHD_LLM_SPLITK / FVHD_LLM_OSPLIT (max. split of o_proj, 0 = never) / FVHD_LLM_FUSENORM
     int max_pos = 0;                       // fvhd_llm_set_max_positions (config.max_position_embeddings): rows of the rotary table
     // A prefill that ran while its stream was being captured put this workspace's pointers into the CALLER's graph.  Such a workspace is
     // never freed when a later call needs a bigger one: it is retired (kept until fvhd_llm_destroy), so the captured graph keeps
@@ -162,7 +165,7 @@ int ensure_ws(fvhd_llm* c, int B, int T, hipStream_t st, bool check_capture)
     const size_t o_h = take((size_t)nrows * c->H * 2), o_xn = take((size_t)nrows * c->H * 2), o_qkv = take((size_t)nrows * c->qkvw * 2),
                  o_att = take((size_t)nrows * c->nh * c->hd * 2), o_act = take((size_t)nrows * c->I * 2), o_last = take((size_t)lb * c->H * 2),
                  o_lastn = take((size_t)lb * c->H * 2), o_rope = take((size_t)np * c->hd * 4),
-                 o_part = take((size_t)kMaxSplits * nrows * c->H * 4);
+                 o_part = take((size_t)nrows * std::max(kMaxSplits * c->H, 2 * c->qkvw) * 4);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return lhip("hipDeviceSynchronize", e);
     if (c->ws) {
@@ -221,6 +224,9 @@ int fvhd_llm_create(fvhd_llm** out, int device, int hidden, int n_layers, int n_
     c->device = device; c->H = hidden; c->L = n_layers; c->nh = n_heads; c->nkv = n_kv_heads; c->hd = head_dim; c->I = intermediate; c->V = vocab;
     c->eps = rms_eps; c->theta = rope_theta; c->qkvw = qkvw;
     if (const char* ev = getenv("FVHD_LLM_SPLITK")) c->down_splits = atoi(ev);      // 0 = never split (A/B)
+    if (const char* ev = getenv("FVHD_LLM_OSPLIT")) c->o_splits = atoi(ev);
+    if (const char* ev = getenv("FVHD_LLM_QKVSPLIT")) c->qkv_splits = atoi(ev);
+    if (const char* ev = getenv("FVHD_LLM_FUSENORM")) c->fuse_norm = atoi(ev);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     c->lo.resize(n_layers);
@@ -397,26 +403,55 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
     if ((size_t)M * H % 4) return lfail("fvhd_llm_prefill: batch * seq_len * hidden must be a multiple of 4");
     LCHECK(fvhd_launch_cast_rows(st, embeds, dtype, c->h, (long)M * H), "cast embeds");
     const size_t cache_layer = (size_t)B * nkv * T * hd * 2;
+    // split-K factor of a GEMM with few output tiles (Mp / 128 x H / 128) - while the tiles of one slice do not fill the chip twice over, K is
+    // split across workgroups (fp32 partials + a deterministic reduce that also adds the residual): down_proj 70 -> ~25 us per layer at the
+    // 0.5 B prefill shape (B = 8 x 285 tokens).  The reduce of a split GEMM also applies the RMSNorm the next operation starts with
+    // (splitk_reduce_norm_kernel, bit-identical to the separate launch): input_layernorm of layer l + 1 behind down_proj of layer l, and -
+    // when o_proj is split too (FVHD_LLM_OSPLIT) - post_attention_layernorm behind o_proj
+    auto pick_splits = [&](int N, int K, int max_sp) {
+        const long tiles = (long)(Mp / 128) * (N / 128);
+        if (N % 128 == 0)
+            for (int sp = kMaxSplits; sp > 1; sp >>= 1)
+                if (sp <= max_sp && tiles * sp <= 512 && K % (64 * sp) == 0) return sp;
+        return 1;
+    };
+    const int down_sp = pick_splits(H, I, c->down_splits > 0 ? kMaxSplits : 1), o_sp = pick_splits(H, nh * hd, c->o_splits);
+    // q|k|v projection: split in two, the reduce applies bias + rotary embedding + the KV-cache copies (splitk_bias_rope_kernel)
+    const int qkv_sp = pick_splits(c->qkvw, H, std::min(c->qkv_splits, 2));
+    bool xn_ready = false;                      // c->xn already holds input_layernorm(c->h) of the coming layer
     for (int l = 0; l < c->L; ++l) {
         const LayerOff& o = c->lo[l];
-        LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln1), Mp, H, c->eps), "rmsnorm 1");
-        LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wqkv, (const float*)(w + o.bqkv), nullptr, nullptr, c->qkv, Mp, c->qkvw, H, EPI_BIAS, FVHD_BF16), "qkv gemm");
-        LCHECK(fvhd_launch_rope(st, c->qkv, (const long*)position_ids, c->rope, k_cache ? (char*)k_cache + l * cache_layer : nullptr,
-                                v_cache ? (char*)v_cache + l * cache_layer : nullptr, M, T, nh, nkv, hd, c->ws_pos, c->theta), "rope");
+        if (!xn_ready) LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln1), Mp, H, c->eps), "rmsnorm 1");
+        void* kc = k_cache ? (char*)k_cache + l * cache_layer : nullptr;
+        void* vc = v_cache ? (char*)v_cache + l * cache_layer : nullptr;
+        if (qkv_sp > 1) {
+            LCHECK(fvhd_launch_gemm_splitk_partials(st, c->xn, w + o.wqkv, c->part, Mp, c->qkvw, H, qkv_sp), "qkv gemm (split-K)");
+            LCHECK(fvhd_launch_splitk_bias_rope(st, c->part, qkv_sp, Mp, (const float*)(w + o.bqkv), c->qkv, (const long*)position_ids, c->rope, kc, vc,
+                                                M, T, nh, nkv, hd, c->ws_pos, c->theta), "qkv reduce + bias + rope");
+        } else {
+            LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wqkv, (const float*)(w + o.bqkv), nullptr, nullptr, c->qkv, Mp, c->qkvw, H, EPI_BIAS, FVHD_BF16), "qkv gemm");
+            LCHECK(fvhd_launch_rope(st, c->qkv, (const long*)position_ids, c->rope, kc, vc, M, T, nh, nkv, hd, c->ws_pos, c->theta), "rope");
+        }
         LCHECK(fvhd_launch_llm_attention(st, c->qkv, c->att, key_valid, B, T, nh, nkv, hd), "attention");
-        LCHECK(fvhd_launch_gemm(st, c->att, w + o.wo, nullptr, nullptr, c->h, c->h, Mp, H, nh * hd, EPI_RESID, FVHD_BF16), "o_proj gemm");
-        LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln2), Mp, H, c->eps), "rmsnorm 2");
+        if (o_sp > 1 && c->fuse_norm) {
+            LCHECK(fvhd_launch_gemm_splitk_norm(st, c->att, w + o.wo, c->h, c->h, c->part, Mp, H, nh * hd, o_sp, (const float*)(w + o.ln2), c->xn, c->eps),
+                   "o_proj gemm (split-K + rmsnorm 2)");
+        } else {
+            if (o_sp > 1) LCHECK(fvhd_launch_gemm_splitk(st, c->att, w + o.wo, c->h, c->h, c->part, Mp, H, nh * hd, o_sp), "o_proj gemm (split-K)");
+            else LCHECK(fvhd_launch_gemm(st, c->att, w + o.wo, nullptr, nullptr, c->h, c->h, Mp, H, nh * hd, EPI_RESID, FVHD_BF16), "o_proj gemm");
+            LCHECK(fvhd_launch_rmsnorm(st, c->h, c->xn, (const float*)(w + o.ln2), Mp, H, c->eps), "rmsnorm 2");
+        }
         LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wgu, nullptr, nullptr, nullptr, c->act, Mp, 2 * I, H, EPI_SWIGLU, FVHD_BF16), "gate_up gemm");
-        // down_proj: few output tiles (Mp / 128 x H / 128), long K = I.  While the tiles of one slice do not fill the chip twice over,
-        // K is split across workgroups (fp32 partials + a deterministic reduce that also adds the residual): 70 -> ~25 us per layer at
-        // the 0.5 B prefill shape (B = 8 x 285 tokens)
-        const long tiles = (long)(Mp / 128) * (H / 128);
-        int splits = 1;
-        if (c->down_splits > 0 && H % 128 == 0)
-            for (int sp = kMaxSplits; sp > 1; sp >>= 1)
-                if (tiles * sp <= 512 && I % (64 * sp) == 0) { splits = sp; break; }
-        if (splits > 1) LCHECK(fvhd_launch_gemm_splitk(st, c->act, w + o.wd, c->h, c->h, c->part, Mp, H, I, splits), "down gemm (split-K)");
-        else LCHECK(fvhd_launch_gemm(st, c->act, w + o.wd, nullptr, nullptr, c->h, c->h, Mp, H, I, EPI_RESID, FVHD_BF16), "down gemm");
+        xn_ready = false;
+        if (down_sp > 1 && c->fuse_norm && l + 1 < c->L) {
+            LCHECK(fvhd_launch_gemm_splitk_norm(st, c->act, w + o.wd, c->h, c->h, c->part, Mp, H, I, down_sp, (const float*)(w + c->lo[l + 1].ln1), c->xn, c->eps),
+                   "down gemm (split-K + rmsnorm 1 of the next layer)");
+            xn_ready = true;
+        } else if (down_sp > 1) {
+            LCHECK(fvhd_launch_gemm_splitk(st, c->act, w + o.wd, c->h, c->h, c->part, Mp, H, I, down_sp), "down gemm (split-K)");
+        } else {
+            LCHECK(fvhd_launch_gemm(st, c->act, w + o.wd, nullptr, nullptr, c->h, c->h, Mp, H, I, EPI_RESID, FVHD_BF16), "down gemm");
+        }
     }
     // logits of the LAST position of every sequence (what generate() reads: outputs.logits[:, -1, :])
     LCHECK(fvhd_launch_gather_rows(st, c->h, c->last, B, T, T - 1, H), "gather last rows");
@@ -456,6 +491,30 @@ int fvhd_op_gemm_splitk(fvhd_stream_t st, const void* A, const void* Wt, const v
     if (splits < 1 || N % 128 || K % (64 * splits)) return lfail("fvhd_op_gemm_splitk: needs N % 128 == 0 and K % (64 * splits) == 0");
     int e = fvhd_launch_gemm_splitk((hipStream_t)st, A, Wt, resid, out, partial, M, N, K, splits);
     return e ? lhip("fvhd_op_gemm_splitk", (hipError_t)e) : 0;
+}
+
+int fvhd_op_gemm_splitk_norm(fvhd_stream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial, int M, int N, int K, int splits,
+                             const float* norm_w, void* norm_out, float eps)
+{
+    if (!A || !Wt || !out || !partial || !norm_w || !norm_out) return lfail("fvhd_op_gemm_splitk_norm: NULL pointer");
+    if (norm_out == out) return lfail("fvhd_op_gemm_splitk_norm: norm_out must not alias out");
+    if (splits < 1 || N % 128 || K % (64 * splits)) return lfail("fvhd_op_gemm_splitk_norm: needs N % 128 == 0 and K % (64 * splits) == 0");
+    int e = fvhd_launch_gemm_splitk_norm((hipStream_t)st, A, Wt, resid, out, partial, M, N, K, splits, norm_w, norm_out, eps);
+    return e ? lhip("fvhd_op_gemm_splitk_norm", (hipError_t)e) : 0;
+}
+
+int fvhd_op_qkv_splitk_rope(fvhd_stream_t st, const void* A, const void* Wt, const float* bias, float* partial, void* qkv, const int64_t* pos,
+                            const float* table, void* k_cache, void* v_cache, int M, int Mp, int K, int T, int n_heads, int n_kv_heads, int head_dim,
+                            int table_positions, float rope_theta, int splits)
+{
+    if (!A || !Wt || !partial || !qkv || !table) return lfail("fvhd_op_qkv_splitk_rope: NULL pointer");
+    const int width = (n_heads + 2 * n_kv_heads) * head_dim;
+    if (splits < 1 || width % 128 || K % (64 * splits) || Mp < M) return lfail("fvhd_op_qkv_splitk_rope: needs width % 128 == 0, K % (64 * splits) == 0, Mp >= M");
+    int e = fvhd_launch_gemm_splitk_partials((hipStream_t)st, A, Wt, partial, Mp, width, K, splits);
+    if (e) return lhip("fvhd_op_qkv_splitk_rope (gemm)", (hipError_t)e);
+    e = fvhd_launch_splitk_bias_rope((hipStream_t)st, partial, splits, Mp, bias, qkv, (const long*)pos, table, k_cache, v_cache, M, T, n_heads, n_kv_heads,
+                                     head_dim, table_positions, rope_theta);
+    return e ? lhip("fvhd_op_qkv_splitk_rope (reduce)", (hipError_t)e) : 0;
 }
 
 int fvhd_op_attention_causal(fvhd_stream_t st, const void* qkv, void* out, const uint8_t* key_valid, int B, int T, int n_heads, int n_kv_heads, int head_dim)

@@ -191,6 +191,44 @@ def test_rope_in_place_and_kv_cache(hd, nh, nkv):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hd,nh,nkv,K,cache", [(64, 14, 2, 896, True), (128, 4, 2, 256, False), (64, 2, 1, 128, True)])
+def test_split_qkv_projection_with_rope_in_its_reduce(hd, nh, nkv, K, cache):
+    """q|k|v projection as a split-K GEMM whose reduce adds the bias, rounds once, rotates q / k and fills the KV cache: bit-identical to the same
+    partial sums + bias -> fvhd_op_rope (whose arithmetic is pinned to apply_rotary_pos_emb above), and close to the plain projection."""
+    from ml_fastvlm_amd.qwen2_prefill import rope_table
+    lib = _lib.load()
+    B, T, splits = 3, 85, 2
+    M, Mp = B * T, (B * T + 127) // 128 * 128
+    width = (nh + 2 * nkv) * hd
+    g = torch.Generator().manual_seed(K + hd)
+    A = _bf(torch.randn(Mp, K, generator=g))
+    W = _bf(torch.randn(width, K, generator=g) * K ** -0.5)
+    bias = torch.randn(width, generator=g)
+    pos = torch.stack([torch.randperm(T, generator=g) for _ in range(B)])
+    pos[0] += 500                                               # one sequence beyond the table
+    table = rope_table(T, hd, 1e6, DEV)
+    ad, wd, bd, pd = A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16), bias.to(DEV), pos.to(DEV)
+    part = torch.empty(splits, Mp, width, device=DEV, dtype=torch.float32)
+    qkv = torch.full((M, width), 7.0, device=DEV, dtype=torch.bfloat16)
+    kc = torch.zeros(B, nkv, T, hd, device=DEV, dtype=torch.bfloat16) if cache else None
+    vc = torch.zeros_like(kc) if cache else None
+    _lib.check(lib.fvhd_op_qkv_splitk_rope(_stream(), _p(ad), _p(wd), _p(bd), _p(part), _p(qkv), _p(pd), _p(table), _p(kc), _p(vc), M, Mp, K, T, nh, nkv, hd,
+                                           T, 1e6, splits), "split qkv + rope")
+    torch.cuda.synchronize()
+    # the same partial sums, reduced here, then the stand-alone rotary kernel
+    ref = ((part[0] + part[1])[:M] + bd).to(torch.bfloat16).contiguous()
+    plain = ref.clone()
+    kc2 = torch.zeros_like(kc) if cache else None
+    vc2 = torch.zeros_like(vc) if cache else None
+    _lib.check(lib.fvhd_op_rope(_stream(), _p(ref), _p(pd), _p(table), _p(kc2), _p(vc2), M, T, nh, nkv, hd, T, 1e6), "rope")
+    torch.cuda.synchronize()
+    assert torch.equal(qkv, ref), "fused reduce + rope differs from reduce -> rope"
+    if cache:
+        assert torch.equal(kc, kc2) and torch.equal(vc, vc2), "KV cache"
+    _close(plain, A[:M] @ W.t() + bias, f"split q|k|v projection {M}x{width}x{K}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hd,nh,nkv,B,T,pad", [(64, 14, 2, 3, 285, "none"), (64, 4, 2, 4, 130, "left"), (64, 2, 1, 2, 64, "right"),
                                               (128, 4, 2, 2, 200, "left"), (128, 2, 2, 3, 17, "none"), (64, 2, 2, 1, 1, "none"),
                                               (64, 2, 1, 5, 300, "left")])        # left padding of up to 97 positions: whole key tiles masked
@@ -242,6 +280,21 @@ def test_gemm_swiglu_and_residual_epilogues():
         _lib.check(lib.fvhd_op_gemm_splitk(_stream(), _p(ad), _p(wd), _p(rd), _p(rd), _p(part), M, N, K, splits), "splitk")
         torch.cuda.synchronize()
         _close(rd, res + A @ W.t(), f"split-K {M}x{N}x{K}/{splits}")
+    # split-K whose reduce also applies the next RMSNorm: both outputs bit-identical to the two separate launches
+    for M, N, K, splits in ((2304, 896, 4864, 4), (2304, 896, 896, 2), (300, 1536, 512, 2), (7, 3584, 256, 1)):
+        A, W, res = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5), _bf(torch.randn(M, N, generator=g))
+        nw = (1.0 + 0.2 * torch.randn(N, generator=g)).to(DEV)
+        ad, wd = A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16)
+        part = torch.empty(splits * M * N, device=DEV, dtype=torch.float32)
+        r0 = res.to(DEV, torch.bfloat16)
+        n0 = torch.empty_like(r0)
+        _lib.check(lib.fvhd_op_gemm_splitk(_stream(), _p(ad), _p(wd), _p(r0), _p(r0), _p(part), M, N, K, splits), "splitk")
+        _lib.check(lib.fvhd_op_rmsnorm(_stream(), _p(r0), _p(n0), _p(nw), M, N, 1e-6), "rmsnorm")
+        r1 = res.to(DEV, torch.bfloat16)
+        n1 = torch.full_like(r1, 7.0)
+        _lib.check(lib.fvhd_op_gemm_splitk_norm(_stream(), _p(ad), _p(wd), _p(r1), _p(r1), _p(part), M, N, K, splits, _p(nw), _p(n1), 1e-6), "splitk + norm")
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1) and torch.equal(n0, n1), f"split-K + norm {M}x{N}x{K}/{splits}"
     # fp32 logits without bias (lm_head), few rows
     A = _bf(torch.randn(8, 896, generator=g))
     W = _bf(torch.randn(1024, 896, generator=g) * 896 ** -0.5)
@@ -301,6 +354,18 @@ def test_prefill_qwen2_05b_shapes_two_layers_b8():
     """BASELINE.json configs[2] shapes - hidden 896, 14 / 2 heads of 64, intermediate 4864, B = 8 x 285 tokens - two layers deep,
     vocabulary cut to 2048 rows (the lm_head GEMM is shape-generic in N)."""
     _compare_prefill(_cfg(hidden=896, layers=2, heads=14, kv=2, inter=4864, vocab=2048), 8, 285, "none", seed=2, layers_tol=1.5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"FVHD_LLM_QKVSPLIT": "2"}, {"FVHD_LLM_QKVSPLIT": "0", "FVHD_LLM_OSPLIT": "0", "FVHD_LLM_FUSENORM": "0"},
+                                 {"FVHD_LLM_SPLITK": "0", "FVHD_LLM_OSPLIT": "0"}])
+def test_prefill_launch_plans_agree_with_transformers(env, monkeypatch):
+    """every launch plan of the decoder layer (fvhd_llm_create reads the switches): split q|k|v projection with bias + rotary embedding in its reduce;
+    no fused norm / no split o_proj (the round-3 plan); no split-K at all"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _compare_prefill(_cfg(hidden=896, layers=2, heads=14, kv=2, inter=4864, vocab=2048), 4, 150, "left", seed=7, layers_tol=1.5e-2)
+    _compare_prefill(_cfg(hidden=256, layers=3, heads=4, kv=2, inter=512, vocab=512), 3, 70, "none", seed=8, layers_tol=1.5e-2)
 
 
 @pytest.mark.gpu

@@ -140,6 +140,19 @@ def bench_dw7cfg():
     raw.fvhd_debug_set_dw7_cfg(1)
 
 
+def bench_dw7small():
+    """dw7x7 stride 1 at the TTFT batch sizes: VALU kernel, default dispatch, and the matrix-core kernel with forced rows per chunk"""
+    raw = _knobs()
+    for B in (8, 1):
+        for cfg, rc in ((0, 0), (1, 0), (5, 4), (5, 8), (5, 16), (5, 32), (5, 64)):
+            raw.fvhd_debug_set_dw7_cfg(cfg)
+            raw.fvhd_debug_set_dwm_rc(rc)
+            print(f"--- B = {B}: dw7 config {cfg} ({'VALU kernel' if cfg == 0 else 'default dispatch' if cfg == 1 else f'matrix-core kernel, {rc} rows per chunk'})")
+            _bench_dw(B, only_k7=True)
+    raw.fvhd_debug_set_dw7_cfg(1)
+    raw.fvhd_debug_set_dwm_rc(0)
+
+
 def _bench_dw(B=32, only_k7=False, only_k3=False):
     for K, S, mult, gelu, Cc, H in ((3, 1, 1, 0, 96, 256), (3, 1, 1, 0, 192, 128), (3, 1, 1, 0, 384, 64),
                                     (7, 1, 1, 0, 96, 256), (7, 1, 1, 0, 192, 128), (7, 1, 1, 0, 384, 64),
@@ -218,4 +231,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()
