@@ -180,6 +180,13 @@ int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* 
  * FVHD_EPI_BIAS (f16 / f32) and FVHD_EPI_NONE (f32: lm_head logits); FVHD_EPI_SWIGLU writes [M, N/2]. */
 int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, const float* ls,
                  const void* resid, void* out, int M, int N, int K, int epilogue, int out_dtype);
+/* the residual GEMM of ConvFFN.fc2 / MHSA.proj (out = resid + ls * (A . Wt^T + bias); mci.py:926 + 1106-1109, :681 + 1185-1187) with K split over
+ * `splits` workgroups per output tile - what fvhd_encode launches instead of fvhd_op_gemm(..., EPI_BIAS_LS_RESID) when fvhd_gemm_splitk_plan(M, N, K)
+ * > 1 (a handful of tiles with a long K: batches of 1-8 images; never in batch-invariant mode).  partial: fp32 scratch [splits][M][N];
+ * N % 128 == 0, K % (64 * splits) == 0; resid may alias out. */
+int fvhd_op_gemm_splitk_ls(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, const float* ls, const void* resid, void* out,
+                           float* partial, int M, int N, int K, int splits);
+int fvhd_gemm_splitk_plan(int M, int N, int K);
 /* LayerNormChannel (mci.py:617-623) on NHWC rows: x,y [M,C] bf16; w,b fp32 [C]. */
 int fvhd_op_layernorm(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* b, int M, int C, float eps);
 /* MHSA core (mci.py:670-679): qkv [B*N,3C] bf16 -> out [B*N,C] bf16, head_dim 32. */

@@ -48,6 +48,8 @@ def _declare(lib) -> None:
         "fvhd_op_dwconv": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci]),
         "fvhd_op_dw7_mfma": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci]),
         "fvhd_op_gemm": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
+        "fvhd_op_gemm_splitk_ls": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci]),
+        "fvhd_gemm_splitk_plan": (ci, [ci, ci, ci]),
         "fvhd_op_layernorm": (ci, [vp, vp, vp, vp, vp, ci, ci, cf]),
         "fvhd_op_attention": (ci, [vp, vp, vp, ci, ci, ci]),
         "fvhd_op_attention_fp8": (ci, [vp, vp, vp, ci, ci, ci]),

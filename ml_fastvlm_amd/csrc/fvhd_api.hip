@@ -21,6 +21,8 @@ int fvhd_launch_preprocess(hipStream_t, const void*, int, int, long, int, int, u
                            void*, const float*, int, void*, int);
 int fvhd_dw7_mfma_supported(int, int, int, int, int);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
+int fvhd_gemm_splitk_plan(int, int, int);
+int fvhd_launch_gemm_splitk_ls(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, float*, int, int, int, int);
 int fvhd_launch_layernorm(hipStream_t, const void*, void*, const float*, const float*, int, int, float);
 int fvhd_launch_stem_fused(hipStream_t, const void*, int, void*, const float*, const float*, const float*, const float*, const void*, const float*, int, int);
 int fvhd_launch_attention(hipStream_t, const void*, void*, int, int, int, int);
@@ -146,6 +148,7 @@ struct fvhd_ctx {
     size_t ws_bytes = 0;
     int ws_batch = 0, ws_hidden = 0;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
+    bool use_splitk = true;      // FVHD_GEMM_SPLITK=0: never split the K of the residual GEMMs (A/B measurements)
     // FVHD_FUSED_STEM: 2 (default) the whole convolutional_stem in ONE launch; 1: stem[0] + stem[1] fused, stem[2] as a GEMM launch (rounds
     // 1-3); 0: three launches through a [B,R/2,R/2,96] HBM tensor.  All three give the same bits.
     int use_fused_stem = 2;
@@ -295,9 +298,11 @@ struct DeviceGuard {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+constexpr size_t kSplitKPartialBytes = (size_t)512 * 128 * 128 * 4;   // fvhd_gemm_splitk_plan: at most 512 (tile, slice) pairs of 128 x 128 fp32
+
 struct Ws {   // workspace carve-up for batch B
     char *X, *T, *A, *H, *tok, *ph, *cast;
-    float *pooled, *scale;
+    float *pooled, *scale, *part;                                    // part: fp32 partial sums of the split-K residual GEMMs (small batches)
     size_t total;
 };
 
@@ -317,6 +322,7 @@ Ws carve(const fvhd_ctx* c, char* base, int B, int hidden)
     w.cast = take(Tn * B * kOutDim * 2);
     w.pooled = (float*)take((size_t)B * (kOutDim + kSeRd) * 4);
     w.scale = (float*)take((size_t)B * kOutDim * 4);
+    w.part = (float*)take(kSplitKPartialBytes);
     w.total = off;
     return w;
 }
@@ -413,9 +419,19 @@ int run_dw(fvhd_ctx* c, hipStream_t st, int cls, const DwW& w, const void* x, vo
 }
 
 int run_gemm(fvhd_ctx* c, hipStream_t st, int cls, const char* wbase, const GemmW& g, const void* A, const float* ls,
-             const void* resid, void* out, int M, int epi, int odt = FVHD_BF16)
+             const void* resid, void* out, int M, int epi, int odt = FVHD_BF16, float* part = nullptr)
 {
     Scope s(c, st, cls);
+    // residual GEMMs with a handful of output tiles and a long K (fc2 / proj at B = 1-8): K split across workgroups.  Not in batch-invariant
+    // mode: the number of slices - the summation order - depends on the batch
+    if (part && epi == FVHD_EPI_BIAS_LS_RESID && odt == FVHD_BF16 && g.has_bias && c->use_splitk && !c->batch_invariant) {
+        const int sp = fvhd_gemm_splitk_plan(M, g.N, g.K);
+        if (sp > 1) {
+            CHECK_LAUNCH(fvhd_launch_gemm_splitk_ls(st, A, wbase + g.w, (const float*)(wbase + g.b), ls, resid, out, part, M, g.N, g.K, sp),
+                         "split-K gemm launch");
+            return 0;
+        }
+    }
     CHECK_LAUNCH(fvhd_launch_gemm(st, A, wbase + g.w, g.has_bias ? (const float*)(wbase + g.b) : nullptr, ls, resid, out,
                                   M, g.N, g.K, epi, odt),
                  "gemm launch");
@@ -448,7 +464,7 @@ int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, in
         return 0;
     }
     if ((e = run_gemm(c, st, C_FC1, c->wdev, f.fc1, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_BIAS_GELU))) return e;
-    return run_gemm(c, st, C_FC2, c->wdev, f.fc2, w.H, c->wp<float>(f.ls), x, x, M, FVHD_EPI_BIAS_LS_RESID);
+    return run_gemm(c, st, C_FC2, c->wdev, f.fc2, w.H, c->wp<float>(f.ls), x, x, M, FVHD_EPI_BIAS_LS_RESID, FVHD_BF16, w.part);
 }
 
 int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X, char*& T, int B, const void* images,
@@ -505,7 +521,7 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
             Scope s(c, st, C_ATT);
             CHECK_LAUNCH(fvhd_launch_attention(st, w.H, T, B, H * H, C, c->attn_fp8), "attention launch");
         }
-        if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID))) return e;
+        if ((e = run_gemm(c, st, C_PROJ, c->wdev, blk.proj, T, c->wp<float>(blk.ls1), X, X, M, FVHD_EPI_BIAS_LS_RESID, FVHD_BF16, w.part))) return e;
         return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, (int)(&sp - c->m.steps.data()));
     }
     case S_DOWN: {   // PatchEmbed (mci.py:739-741)
@@ -644,6 +660,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->R = image_size;
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_GEMM_SPLITK")) c->use_splitk = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_FUSED_STEM")) c->use_fused_stem = atoi(ev);
     if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_GRAPH")) c->graph = atoi(ev) != 0;
@@ -1035,6 +1052,14 @@ int fvhd_op_gemm(fvhd_stream_t st, const void* A, const void* Wt, const float* b
 {
     int e = fvhd_launch_gemm((hipStream_t)st, A, Wt, bias, ls, resid, out, M, N, K, epilogue, out_dtype);
     return e ? hip_fail("fvhd_op_gemm", (hipError_t)e) : 0;
+}
+
+int fvhd_op_gemm_splitk_ls(fvhd_stream_t st, const void* A, const void* Wt, const float* bias, const float* ls, const void* resid, void* out,
+                           float* partial, int M, int N, int K, int splits)
+{
+    if (!A || !Wt || !bias || !ls || !resid || !out || !partial) return fail("fvhd_op_gemm_splitk_ls: NULL pointer");
+    int e = fvhd_launch_gemm_splitk_ls((hipStream_t)st, A, Wt, bias, ls, resid, out, partial, M, N, K, splits);
+    return e ? hip_fail("fvhd_op_gemm_splitk_ls", (hipError_t)e) : 0;
 }
 
 int fvhd_op_layernorm(fvhd_stream_t st, const void* x, void* y, const float* w, const float* b, int M, int C, float eps)

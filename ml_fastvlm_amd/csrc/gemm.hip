@@ -610,6 +610,50 @@ extern "C" int fvhd_launch_gemm_splitk_norm(hipStream_t st, const void* A, const
     return (int)hipGetLastError();
 }
 
+// The tower's residual GEMMs (ConvFFN.fc2, MHSA.proj: out = resid + ls * (A . Wt^T + bias), EPI_BIAS_LS_RESID) at SMALL batches: a handful of
+// output tiles with a long K (B = 1, stage 2: 96 tiles of 24 K steps on 256 CUs; stage 4: 24 tiles of 96).  Same split as above, the reduce applies
+// the epilogue in the epilogue's own order.
+__global__ __launch_bounds__(256) void splitk_reduce_ls_kernel(const float* __restrict__ part, const float* __restrict__ bias, const float* __restrict__ ls,
+                                                               const bf16* resid, bf16* out, long mn, int N, int splits)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= mn) return;
+    const int n = (int)(i % N);
+    f32x4 v = *(const f32x4*)(part + i);
+    for (int s = 1; s < splits; ++s) v += *(const f32x4*)(part + (size_t)s * mn + i);
+    v = v + *(const f32x4*)(bias + n);
+    const f32x4 r = bf4_to_f32(*(const bf16x4*)(resid + i));
+    v = r + *(const f32x4*)(ls + n) * v;
+    *(bf16x4*)(out + i) = f32_to_bf4(v);
+}
+
+// how many K slices fvhd_launch_gemm_splitk_ls should use for this shape (1 = the plain GEMM is the better launch): the largest power of two
+// that keeps tiles x slices within two workgroups per CU and leaves every slice at least 6 K steps of 64
+extern "C" int fvhd_gemm_splitk_plan(int M, int N, int K)
+{
+    if (M <= 0 || N % 128 || K % 64) return 1;
+    const long tiles = (long)((M + 127) / 128) * (N / 128);
+    for (int sp = 16; sp > 1; sp >>= 1)
+        if (tiles * sp <= 512 && (K / 64) % sp == 0 && K / sp >= 384) return sp;
+    return 1;
+}
+
+// A [M, K], Wt [N, K] bf16, bias / ls fp32 [N], resid [M, N] bf16 (may alias out), out [M, N] bf16; partial: fp32 scratch [splits][M][N]
+extern "C" int fvhd_launch_gemm_splitk_ls(hipStream_t st, const void* A, const void* Wt, const float* bias, const float* ls, const void* resid, void* out,
+                                          float* partial, int M, int N, int K, int splits)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || N % 128 || K % (64 * splits) || !partial || !bias || !ls || !resid) return (int)hipErrorInvalidValue;
+    const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
+    hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
+                       nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const long mn = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_ls_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, partial, bias, ls, (const bf16*)resid, (bf16*)out,
+                       mn, N, splits);
+    return (int)hipGetLastError();
+}
+
 // only the partials [splits][M][N] (fp32): for a caller with its own reduce (llm.hip: bias + rotary embedding behind the q|k|v projection)
 extern "C" int fvhd_launch_gemm_splitk_partials(hipStream_t st, const void* A, const void* Wt, float* partial, int M, int N, int K, int splits)
 {

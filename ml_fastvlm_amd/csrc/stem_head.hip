@@ -413,15 +413,29 @@ extern "C" int fvhd_launch_stem_fused(hipStream_t st, const void* img, int dtype
 }
 
 // ---- SE: global average pool over the T tokens of each image -------------------------------------
-// y [B, T, C] bf16 -> pooled [B, C] fp32.  grid (C/256, B), one thread per channel.
+// y [B, T, C] bf16 -> pooled [B, C] fp32.  grid (C/128, B); a workgroup = 16 channel groups of 8 (one 16-B load each) x 16 token slices: every
+// thread sums T/16 tokens (independent loads in flight instead of one dependent 2-B load per token: 75 -> ~8 us at B = 32), the slices
+// are added in order through LDS.
 __global__ __launch_bounds__(256) void se_pool_kernel(const bf16* __restrict__ y, float* __restrict__ pooled, int T, int C)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
-    const bf16* p = y + (size_t)b * T * C + c;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += (float)p[(size_t)t * C];
-    pooled[(size_t)b * C + c] = s / (float)T;
+    __shared__ float red[16][128 + 4];
+    const int cg = threadIdx.x & 15, ts = threadIdx.x >> 4, b = blockIdx.y;
+    const int c = blockIdx.x * 128 + cg * 8;
+    f32x8 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const bf16* p = y + (size_t)b * T * C + c;
+#pragma unroll 4
+        for (int t = ts; t < T; t += 16) s += bf8_to_f32(*(const bf16x8*)(p + (size_t)t * C));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[ts][cg * 8 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 128 && blockIdx.x * 128 + (int)threadIdx.x < C) {
+        float a = red[0][threadIdx.x];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) a += red[i][threadIdx.x];
+        pooled[(size_t)b * C + blockIdx.x * 128 + threadIdx.x] = a / (float)T;
+    }
 }
 
 // ---- SE MLP: scale[b] = sigmoid(We . relu(Wr . pooled[b] + br) + be) -----------------------------
@@ -488,7 +502,7 @@ extern "C" int fvhd_launch_se_head(hipStream_t st, const void* y, float* pooled,
                                    int B, int T, int C, int RD)
 {
     if (C % 8 || RD % 4 || RD > 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(se_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, (const bf16*)y, pooled, T, C);
+    hipLaunchKernelGGL(se_pool_kernel, dim3((C + 127) / 128, B), dim3(256), 0, st, (const bf16*)y, pooled, T, C);
     // `pooled` is [B, C + RD]: the pooled row followed by the SE hidden row
     float* hidden = pooled + (size_t)B * C;
     hipLaunchKernelGGL(se_reduce_kernel, dim3((RD + 3) / 4, B), dim3(256), 0, st, pooled, wr, br, hidden, C, RD);

@@ -136,6 +136,34 @@ def test_gemm_inplace_residual_and_f32_out():
     _close(got16, _bf(A).float() @ _bf(W).float().t() + bias, rtol=2e-3, atol_rms=2e-3, what="gemm f16 out")
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 384, 1536), (1024, 768, 3072), (256, 1536, 6144), (1024, 768, 768), (300, 1536, 1536), (2048, 1536, 6144)])
+def test_gemm_split_k_residual(M, N, K):
+    """fc2 / proj at small batches: the K of a GEMM with few output tiles is split over workgroups (fp32 partials, ordered reduce with the
+    bias + layer-scale + residual epilogue).  Checked against the fp32 reference like the plain GEMM, and against the plain GEMM itself."""
+    lib = _lib.load()
+    sp = lib.fvhd_gemm_splitk_plan(M, N, K)
+    assert sp > 1 and K % (64 * sp) == 0 and -(-M // 128) * (N // 128) * sp <= 512, sp
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    bias, ls, resid = _rand(N, seed=3, scale=0.1), torch.rand(N, generator=torch.Generator().manual_seed(4)), _rand(M, N, seed=5)
+    ad, wd, rd = A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16), resid.to(DEV, torch.bfloat16)
+    bd, ld = bias.to(DEV), ls.to(DEV)
+    part = torch.empty(sp * M * N, device=DEV, dtype=torch.float32)
+    out = rd.clone()                                               # in place, as the tower calls it
+    _lib.check(lib.fvhd_op_gemm_splitk_ls(_stream(), _p(ad), _p(wd), _p(bd), _p(ld), _p(out), _p(out), _p(part), M, N, K, sp), "split-K gemm")
+    torch.cuda.synchronize()
+    want = _bf(resid).float() + ls * (_bf(A).float() @ _bf(W).float().t() + bias)
+    _close(out, want, what=f"split-K gemm {M}x{N}x{K}/{sp}")
+    plain = _gemm(A, W, bias, ls, resid, _lib.EPI_BIAS_LS_RESID)
+    d = (out.float() - plain.float()).abs().max().item()
+    assert d <= 2 ** -6 * max(1.0, want.abs().max().item()), d      # the two summation orders agree to a bf16 ulp of the largest value
+
+
+def test_gemm_split_k_plan_leaves_large_launches_alone():
+    lib = _lib.load()
+    for M, N, K in ((32768, 768, 3072), (8192, 1536, 6144), (131072, 384, 1536), (4096, 192, 768), (4096, 384, 100)):
+        assert lib.fvhd_gemm_splitk_plan(M, N, K) == 1, (M, N, K)
+
+
 def test_gemm_rejects_bad_shapes():
     lib = _lib.load()
     a = torch.zeros(8, 40, dtype=torch.bfloat16, device=DEV)
