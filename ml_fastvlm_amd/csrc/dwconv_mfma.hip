@@ -44,8 +44,13 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int DWM_P = 80;        // pitch (px) of one channel row of the transposed image: (P/2) % 64 == 40 -> the 16 channels of an A read fall on 8 bank groups (2-way = the 512-B minimum)
-constexpr int DWM_RS = 4;        // raw-row ring depth
-#ifndef DWM_ABL                  // timing-only ablations (wrong results; bit 0: no transposing writes, 1: no staging writes, 2: no per-row barrier)
+#ifndef DWM_RS_
+#define DWM_RS_ 4
+#endif
+constexpr int DWM_RS = DWM_RS_;  // raw-row ring depth
+#ifndef DWM_ABL                  // timing-only ablations (wrong results; bit 0: no transposing writes, 1: no staging writes, 2: no per-row barrier,
+                                 // 3: no MFMAs, 4: no output stores, 5: no LDS-DMA inside the row loop, 6: no LDS reads inside the row loop,
+                                 // 7: ONE output staging buffer (racy) - with -DDWM_RS_=5 the deeper ring in the same LDS)
 #define DWM_ABL 0
 #endif
 // NW waves per workgroup = NW adjacent channel groups = 16 NW channels: 4 (64 channels = one 128-B line per pixel; C = 192, 384, ...)
@@ -55,7 +60,8 @@ template <int NW> struct DwmCfg {
     static constexpr int OPX = PXB + 16;                      // output staging: one pixel + 16 B pad (the 4 pixels of one ds_write_b16 on 4 bank groups)
     static constexpr int HALO = 64 * PXB;                     // byte offset of the halo pixels inside a raw row
     static constexpr int RAWB = 72 * PXB, OB = 64 * OPX, TB = 16 * DWM_P * 2;       // TB: one transposed image; two per wave
-    static constexpr int LDS = DWM_RS * RAWB + 2 * OB + NW * 2 * TB;
+    static constexpr int NOB = (DWM_ABL & 128) ? 1 : 2;
+    static constexpr int LDS = DWM_RS * RAWB + NOB * OB + NW * 2 * TB;
 };
 
 FVHD_DEV u16 f32_to_bf16_rne(float f) { unsigned u = __float_as_uint(f); u += 0x7fff + ((u >> 16) & 1); return (u16)(u >> 16); }
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* raw = smem;                                       // [RS][64 interior px | 8 halo px][PXB]  (NW = 4: chunks permuted inside every 1-KiB piece)
     char* O = smem + RS * RAWB;                             // [2][64 px][OPX]
-    u16* T = (u16*)(smem + RS * RAWB + 2 * OB + wv * 2 * TBY);  // per wave: [2][16 ch][P px], column 0..3 left halo, 4..67 strip, 68..71 right halo
+    u16* T = (u16*)(smem + RS * RAWB + K::NOB * OB + wv * 2 * TBY);  // per wave: [2][16 ch][P px], column 0..3 left halo, 4..67 strip, 68..71 right halo
     const int blk = lane >> 2, q = lane & 3;
     const int NCB = C / CW;
     int L = blockIdx.x;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
         }
     };
     auto stage_write1 = [&](const unsigned (&pk)[2 * NT], int ob, int j) {  // j = 0..15: pixel 16 (j / 4) + 4 (j % 4) + q
-        u16* Ow = (u16*)(O + ob * OB + q * OPX + wv * 32 + blk * 2);
+        u16* Ow = (u16*)(O + (ob & (K::NOB - 1)) * OB + q * OPX + wv * 32 + blk * 2);
         const unsigned v = pk[j >> 1];
         Ow[(16 * (j >> 2) + 4 * (j & 3)) * (OPX / 2)] = (j & 1) ? (u16)(v >> 16) : (u16)v;
     };
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     };
     auto o_read = [&](u32x4 (&o)[2], int ob) {
         // same element type as the ds_write_b16 side (strict aliasing: a u32x4 load was hoisted above the u16 stores)
-        o[0] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + ord0));
-        o[1] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + ob * OB + ord1));
+        o[0] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + (ob & (K::NOB - 1)) * OB + ord0));
+        o[1] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + (ob & (K::NOB - 1)) * OB + ord1));
     };
     auto o_store = [&](const u32x4 (&o)[2], int yo) {
         const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;     // valid offsets are < 2^31: the flags are OR-ed in
@@ -235,10 +241,17 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
             s16x4 a[3][NT];                                     // A operands of the three segments
             u32x4 tv[3], ov[2];
             unsigned pk[2 * NT];
+            if (DWM_ABL & 64) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { a[0][t] = s16x4{1, 2, 3, 4}; a[1][t] = a[0][t]; a[2][t] = a[0][t]; asm volatile("" : "+v"(a[0][t]), "+v"(a[1][t]), "+v"(a[2][t])); }
+                tv[0] = tv[1] = tv[2] = u32x4{1, 2, 3, 4}; ov[0] = ov[1] = tv[0];
+                asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(ov[0]), "+v"(ov[1]));
+            } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) a[0][t] = *(const s16x4*)&rd[tb * (16 * P) + 16 * t];
             tr_read(tv, nslot);
             o_read(ov, ob ^ 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // 84 MFMAs in the order (segment s, tap row ky = 6..0, tile t): 27 independent MFMAs between two updates of one
             // accumulator; ky = 6 first, so the slot staged at the end gets its last update earliest.  "+v" ties the accumulator in
@@ -252,19 +265,21 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                 // a slot starts its life (output row r + 3: ky = 0 of segment 0) with C = the bias quad instead of being re-initialised
                 // by VALU moves: the register allocator placed those moves directly in front of the MFMA that reads them, and an
                 // inline-asm MFMA gets no VALU-write -> MFMA-read wait states from the compiler (wrong sums in 2 of 4 registers)
-                if (s == 0 && ky == 0)
+                if (DWM_ABL & 8)
+                    asm volatile("" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[s][t]), "v"(bop[ky][s]));
+                else if (s == 0 && ky == 0)
                     asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[s][t]), "v"(bop[ky][s]), "v"(biasq));
                 else
                     asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[s][t]), "v"(bop[ky][s]));
-                if (k == 2) {
+                if (!(DWM_ABL & 64) && k == 2) {
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) a[1][tt] = *(const s16x4*)&rd[tb * (16 * P) + 16 * tt + 4];
                 }
-                if (k == 5) o_store(ov, r - 4);                 // staged in the previous iteration
-                if (k == 8) dma(min(r + RS, r_hi - 1), slot);   // row r's slot: every wave transposed it before this iteration's barrier
+                if (!(DWM_ABL & 16) && k == 5) o_store(ov, r - 4);                 // staged in the previous iteration
+                if (!(DWM_ABL & 32) && k == 8) dma(min(r + RS, r_hi - 1), slot);   // row r's slot: every wave transposed it before this iteration's barrier
                 if (!(DWM_ABL & 1) && k >= 10 && k < 18) tr_write1(tv, tb ^ 1, 0, k - 10);
                 if (!(DWM_ABL & 1) && k >= 18 && k < 26) tr_write1(tv, tb ^ 1, 1, k - 18);
-                if (k == 30) {
+                if (!(DWM_ABL & 64) && k == 30) {
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) a[2][tt] = *(const s16x4*)&rd[tb * (16 * P) + 16 * tt + 8];
                 }

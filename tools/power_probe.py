@@ -106,7 +106,7 @@ def gemm():
 
 
 def dw7(Cc=192):
-    B, H = 32, {96: 256, 192: 128, 384: 64}[Cc]
+    B, H = int(os.environ.get("FVHD_PROBE_B", "32")), {96: 256, 192: 128, 384: 64}[Cc]
     x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
     y = torch.empty_like(x)
     w = torch.randn(49, Cc, device=DEV)
