@@ -97,6 +97,9 @@ final)      # evidence of the final binary: bench line, small batches, PMC passe
     timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-ttft > ${O}_bench_b1.json 2>/dev/null; cut -c1-200 ${O}_bench_b1.json
     timeout 300 python tools/power_probe.py ffn384 ffn192 ffn96 stem attn 2>/dev/null | tee ${O}_final_power.log
     bash tools/run_pmc.sh ${TAG}
+    # kernel trace of the TTFT path (encode B = 8 -> splice -> Qwen2-0.5B prefill): per-layer launch times of the prefill
+    timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_ttft_trace -o ttft -- python bench.py --ttft --steps 4 --warmup 1 > gpurun_out/${TAG}_ttft_trace.log 2>&1
+    python tools/rocpd_summary.py gpurun_out/${TAG}_ttft_trace/ttft_results.db > ${O}_ttft_kernel_trace.md 2>&1; rm -rf gpurun_out/${TAG}_ttft_trace; head -30 ${O}_ttft_kernel_trace.md | cut -c1-160
     ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
