@@ -219,6 +219,27 @@ def bench_gemm(B=32):
     raw.fvhd_debug_set_gemm_v2(1)
 
 
+def bench_gemmsmall():
+    """the tower's GEMM route at B = 1 and B = 8 (stages 1-4 fc1 / fc2 below the fused-FFN threshold, qkv, proj): v1 / 256x128 / 256x256 / default"""
+    raw = _knobs()
+    for B in (1, 8):
+        shapes = [("s3 qkv", B * 1024, 2304, 768, 0), ("s3 proj", B * 1024, 768, 768, 3), ("s3 fc1", B * 1024, 3072, 768, 2), ("s3 fc2", B * 1024, 768, 3072, 3),
+                  ("s4 qkv", B * 256, 4608, 1536, 0), ("s4 fc1", B * 256, 6144, 1536, 2), ("s4 fc2", B * 256, 1536, 6144, 3)]
+        if B == 1:
+            shapes = [("s1 fc1", 16384, 768, 192, 2), ("s1 fc2", 16384, 192, 768, 3), ("s2 fc1", 4096, 1536, 384, 2), ("s2 fc2", 4096, 384, 1536, 3)] + shapes
+        for v2, nm in ((0, "v1"), (2, "256x128"), (3, "256x256"), (1, "default")):
+            raw.fvhd_debug_set_gemm_v2(v2)
+            print(f"--- B = {B}, gemm: {nm}")
+            for name, M, N, K, epi in shapes:
+                A = torch.randn(M, K).to(DEV, torch.bfloat16)
+                W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
+                bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
+                out = torch.randn(M, N).to(DEV, torch.bfloat16)
+                t = timeit(lambda: _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(out), p(out), M, N, K, epi, 2)))
+                print(f"gemm {name:8s} M={M:6d} N={N:5d} K={K:5d} epi={epi}: {t*1e6:8.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+    raw.fvhd_debug_set_gemm_v2(1)
+
+
 def bench_attn(B=32):
     for N, Cc in ((1024, 768), (256, 1536), (2304, 768), (576, 1536)):
         qkv = torch.randn(B * N, 3 * Cc).to(DEV, torch.bfloat16)
@@ -231,4 +252,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "attn": bench_attn}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn}[w]()
