@@ -726,7 +726,12 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
         // ties or loses below (N = 768: 64 -> 74 us) and with 1.3 rounds (prefill gate|up, 342 tiles: 59 -> 65).  All three kernels
         // produce identical bits (same K order per output element).
         const bool use256 = g_gemm_v2 == 3 ? t256 > 0 : (g_gemm_v2 == 1 && N >= 2304 && t256 >= 448);
-        const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && t128 >= 512);
+        // 256 x 128 (one workgroup per CU): from two rounds of tiles on, unless the last round is mostly empty (B = 8 stage-3 qkv, 576 tiles = 2.25
+        // rounds: v1 46.9 vs 52.1 us; the prefill's gate|up, 684 tiles = 2.67 rounds, stays: 58.7 vs 62.3) - and already from half a round when K is
+        // long (K >= 3072: B = 8 stage-3 fc2 64.7 -> 55.5 us, the 0.5B projector's fc 66.5 -> 54.7; profiles/r04_gemm_small_batch.log, r03_gemm_tiles.log)
+        const long long rounds128 = (t128 + 255) / 256;
+        const bool full_enough = t128 >= 1024 || t128 * 5 >= rounds128 * 256 * 4;            // >= 80 % of the slots of its rounds
+        const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && ((t128 >= 512 && full_enough) || (t128 >= 128 && K >= 3072)));
         // ping-pong kernel: same tile, +0-6 % over the plain 256 x 256 kernel, the more the longer K (profiles/r03_gemm_tiles.log: stage-4 fc2
         // K = 6144 185 -> 177 us, 7B projector K = 3584 243 -> 228 us = 0.92 PF/s; K = 768 shapes tie) - taken for K >= 3072
         if ((g_gemm_v2 == 4 && t256 > 0) || (g_gemm_v2 == 1 && K >= 3072 && t256 >= 128))
