@@ -306,6 +306,90 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
     gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 16 * MF, n0 + wn * 64, lr, g);
 }
 
+// v1s (round 4): v1's 128 x 128 tile / 4 waves (2 x 2, 64 x 64 each) with the operands streamed by LDS-DMA through a FOUR-stage ring of 32-KB
+// K tiles (three tiles in flight per workgroup, one barrier per K tile) - for launches with at most ~one tile per CU, where v1's single
+// register-prefetched tile leaves every K step exposed to one full L2 / HBM round trip (the prefill's q|k|v projection: 162 tiles of 14 K steps =
+// 16.9 us, 1.2 us per step for 0.1 us of MFMA time; the tower's GEMMs at B = 1).  Same LDS image, fragment reads, MFMA order and epilogue as
+// v1 - identical bits.  Split-K aware like v1 (blockIdx.y = K slice, ldk = row stride, fp32 partials).  Needs M % 128 == 0 (rows are not
+// clamped: LDS-DMA), N % 128 == 0, K % 64 == 0.
+constexpr int kG128Stages = 4, kG128Stage = (128 + 128) * 64 * 2, kG128Lds = kG128Stages * kG128Stage;
+template <int EPI, int ODT>
+__global__ __launch_bounds__(256, 1) void gemm128s_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ ls, const bf16* resid, void* out_, int M, int N, int K, int tiles_n, int nwg, int ldk)
+{
+    constexpr int BM = 128, BK = 64, MF = 4, NF = 4, RS = kG128Stages, STAGE = kG128Stage, RPP = 8, PA = 4, PW = 4;
+    A += (size_t)blockIdx.y * K;
+    Wt += (size_t)blockIdx.y * K;
+    void* out = ODT == FVHD_F32 ? (void*)((float*)out_ + (size_t)blockIdx.y * M * N) : out_;
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, g = lane >> 4;
+    const int L = xcd_remap(blockIdx.x, nwg);               // v1's super-tile order
+    constexpr int GN = 8;
+    const int tiles_m = nwg / tiles_n;
+    const int grp = L / (tiles_m * GN), rem = L - grp * tiles_m * GN;
+    const int wg = min(GN, tiles_n - grp * GN);
+    const int tm = rem / wg, tn = grp * GN + (rem - tm * wg);
+    const int m0 = tm * BM, n0 = tn * 128;
+
+    // lane l of a 1-KiB piece (8 rows x 128 B) fetches chunk (l & 7) ^ swizzle(row) of row l >> 3; the key depends on the piece's parity only
+    const int rip = lane >> 3;
+    unsigned va[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        va[par] = (unsigned)((rip * ldk + (((lane & 7) ^ lds_swz<BK>(par * RPP + rip)) * 8)) * 2);
+    const char* abase = (const char*)(A + (size_t)(m0 + wave * RPP * PA) * ldk);
+    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * RPP * PW) * ldk);
+    const unsigned lds0 = lds_addr(lds2);
+    auto issue = [&](int kt) {
+        const unsigned st = lds0 + (kt % RS) * STAGE;
+        const size_t ko = (size_t)kt * BK * 2;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) glds_piece(va[j & 1], abase + (size_t)j * RPP * ldk * 2 + ko, st + (wave * PA + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) glds_piece(va[j & 1], wbase + (size_t)j * RPP * ldk * 2 + ko, st + BM * BK * 2 + (wave * PW + j) * 1024);
+    };
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+#pragma unroll
+    for (int i = 0; i < RS - 1; ++i)
+        if (i < nk) issue(i);
+    for (int kt = 0; kt < nk; ++kt) {
+        // own pieces of tile kt have landed when at most the later tiles' pieces are outstanding (loads only in this loop; in order)
+        const int later = nk - 1 - kt < RS - 2 ? nk - 1 - kt : RS - 2;
+        if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PA + PW)) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // tile kt visible to every wave; tile kt - 1 fully consumed
+        if (kt + RS - 1 < nk) issue(kt + RS - 1);     // into the stage tile kt - 1 occupied
+        const char* ldsA = lds2 + (kt % RS) * STAGE;
+        const char* ldsW = ldsA + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[MF], wf[NF];
+            const int ks = kk * 4 + g;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(ldsA + lds_off<BK>(wm * 64 + i * 16 + lr, ks));
+#pragma unroll
+            for (int j = 0; j < NF; ++j) wf[j] = *(const bf16x8*)(ldsW + lds_off<BK>(wn * 64 + j * 16 + lr, ks));
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 64, n0 + wn * 64, lr, g);
+}
+
 // v4 (round 3, experiment): "ping-pong" 256 x 256 tile.  The 8 waves form two groups (rows 0-127 / 128-255 of the tile; one wave of each
 // group per SIMD) that run ONE PHASE APART: while a group issues the fragment reads of a half K-tile (12 ds_read_b128 per wave) and its
 // LDS-DMA pieces, the other group runs the 32 MFMAs of its own half K-tile out of registers, and a barrier ends every phase - each
@@ -525,6 +609,63 @@ static hipError_t dispatch_gemm256_bk32(hipStream_t st, const bf16* a, const bf1
 }
 #endif
 
+// 128 x 128 streaming kernel (v1s).  K = the K range of ONE slice, ldk = the row stride, splits = gridDim.y (1 for a plain GEMM)
+template <int EPI, int ODT>
+static hipError_t launch_gemm128s(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls, const bf16* resid, void* out,
+                                  int M, int N, int K, int splits, int ldk)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm128s_kernel<EPI, ODT>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    const int tiles_m = M / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm128s_kernel<EPI, ODT>), dim3(nwg, splits), dim3(256), kG128Lds, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg, ldk);
+    return hipGetLastError();
+}
+
+static hipError_t dispatch_gemm128s(hipStream_t st, const bf16* a, const bf16* w, const float* bias, const float* ls, const bf16* r, void* out,
+                                    int M, int N, int K, int epi)
+{
+    switch (epi) {
+    case EPI_NONE: return launch_gemm128s<EPI_NONE, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K, 1, K);
+    case EPI_BIAS: return launch_gemm128s<EPI_BIAS, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K, 1, K);
+    case EPI_BIAS_GELU: return launch_gemm128s<EPI_BIAS_GELU, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K, 1, K);
+    case EPI_BIAS_LS_RESID: return launch_gemm128s<EPI_BIAS_LS_RESID, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K, 1, K);
+    case EPI_RESID: return launch_gemm128s<EPI_RESID, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K, 1, K);
+    case EPI_SWIGLU: return launch_gemm128s<EPI_SWIGLU, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K, 1, K);
+    }
+    return hipErrorInvalidValue;
+}
+
+// the fp32 partials [splits][M][N] of a split-K GEMM: v1, or v1s when its shape rules hold and the launch is small enough for it
+// measured (tools/bench_ops.py gemmsmall, profiles/r04_gemm_v1s.log): ahead of v1 up to ~200 workgroups - prefill q|k|v 16.9 -> 15.0 us, unsplit
+// down_proj 63.4 -> 52.6, the tower at B = 1: stage-2 fc2 24.6 -> 21.3, stage-4 qkv / fc1 22.0 / 24.9 -> 19.0 / 21.5 - behind it from ~300 on
+// (v1 then has 2-4 workgroups per CU covering each other's latency: stage-2 fc1 at B = 1, 384 tiles, 16.1 -> 21.0), and behind v1 for the
+// slices of a split-K launch with 250-500 workgroups (llm down / 4: 39.7 -> 43.0)
+#ifndef FVHD_GEMM128S_MAX_TILES
+#define FVHD_GEMM128S_MAX_TILES 224        // workgroups of one launch up to which v1s is taken (0 = never)
+#endif
+static bool take_gemm128s(int M, int N, int K, long workgroups)
+{
+    if (M % 128 || N % 128 || K % 64 || K < 128) return false;
+    if (g_gemm_v2 == 10) return true;
+    return g_gemm_v2 == 1 && workgroups <= FVHD_GEMM128S_MAX_TILES;
+}
+
+static hipError_t launch_splitk_partials(hipStream_t st, const void* A, const void* Wt, float* partial, int M, int N, int K, int splits)
+{
+    const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
+    if (take_gemm128s(M, N, ks, (long)nwg * splits))
+        return launch_gemm128s<EPI_NONE, FVHD_F32>(st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr, nullptr, (void*)partial, M, N, ks, splits, K);
+    hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
+                       nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
+    return hipGetLastError();
+}
+
 template <int NF, int BK, int EPI, int ODT>
 static hipError_t launch_gemm(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
                               const bf16* resid, void* out, int M, int N, int K)
@@ -596,10 +737,7 @@ extern "C" int fvhd_launch_gemm_splitk_norm(hipStream_t st, const void* A, const
 {
     if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || N % 128 || K % (64 * splits) || !partial) return (int)hipErrorInvalidValue;
     if ((norm_w == nullptr) != (norm_out == nullptr) || (norm_out && norm_out == out)) return (int)hipErrorInvalidValue;
-    const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
-    hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
-                       nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_splitk_partials(st, A, Wt, partial, M, N, K, splits);
     if (e != hipSuccess) return (int)e;
     const long mn = (long)M * N;
     if (norm_w)
@@ -628,13 +766,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_ls_kernel(const float* __re
 }
 
 // how many K slices fvhd_launch_gemm_splitk_ls should use for this shape (1 = the plain GEMM is the better launch): the largest power of two
-// that keeps tiles x slices within two workgroups per CU and leaves every slice at least 6 K steps of 64
+// that keeps tiles x slices within two workgroups per CU and leaves every slice at least 6 K steps of 64, for K >= 2048 (stage-2 fc2 at B = 1,
+// K = 1536: 23.5 us split in four against 21.3 us on the streaming 128 x 128 kernel)
 extern "C" int fvhd_gemm_splitk_plan(int M, int N, int K)
 {
     if (M <= 0 || N % 128 || K % 64) return 1;
     const long tiles = (long)((M + 127) / 128) * (N / 128);
     for (int sp = 16; sp > 1; sp >>= 1)
-        if (tiles * sp <= 512 && (K / 64) % sp == 0 && K / sp >= 384) return sp;
+        if (tiles * sp <= 512 && (K / 64) % sp == 0 && K / sp >= 384 && K >= 2048) return sp;     // (K < 2048: the reduce costs more than the K steps saved - v1s unsplit)
     return 1;
 }
 
@@ -643,10 +782,7 @@ extern "C" int fvhd_launch_gemm_splitk_ls(hipStream_t st, const void* A, const v
                                           float* partial, int M, int N, int K, int splits)
 {
     if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || N % 128 || K % (64 * splits) || !partial || !bias || !ls || !resid) return (int)hipErrorInvalidValue;
-    const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
-    hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
-                       nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_splitk_partials(st, A, Wt, partial, M, N, K, splits);
     if (e != hipSuccess) return (int)e;
     const long mn = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_ls_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, partial, bias, ls, (const bf16*)resid, (bf16*)out,
@@ -658,10 +794,7 @@ extern "C" int fvhd_launch_gemm_splitk_ls(hipStream_t st, const void* A, const v
 extern "C" int fvhd_launch_gemm_splitk_partials(hipStream_t st, const void* A, const void* Wt, float* partial, int M, int N, int K, int splits)
 {
     if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || N % 128 || K % (64 * splits) || !partial) return (int)hipErrorInvalidValue;
-    const int tiles_m = (M + 127) / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n, ks = K / splits;
-    hipLaunchKernelGGL((gemm_kernel<4, 64, EPI_NONE, FVHD_F32>), dim3(nwg, splits), dim3(256), 0, st, (const bf16*)A, (const bf16*)Wt, nullptr, nullptr,
-                       nullptr, (void*)partial, M, N, ks, tiles_n, nwg, K);
-    return (int)hipGetLastError();
+    return (int)launch_splitk_partials(st, A, Wt, partial, M, N, K, splits);
 }
 
 extern "C" int fvhd_launch_gemm_splitk(hipStream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial,
@@ -706,8 +839,11 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     // (tools/bench_ops.py gemm, profiles/r02_gemm_v1_v2.log) fc1 272 -> 264 us, fc2 (K = 3072) 215 -> 196, stage-5 qkv 177 -> 155,
     // projector fc 68 -> 56; with 384 tiles (stage-5 proj / fc2, 1.5 rounds) v1 stays ahead.  A 4-wave variant with 128 x 64 per
     // wave (fewer fragment reads, one wave per SIMD) was 10-25 % slower: nothing covers the LDS read latency.
-    // g_gemm_v2 (debug build): 0 = v1 only, 1 = the rule below, 2 = the 256 x 128 tile wherever it is legal, 3 = the 256 x 256 tile wherever legal,
+    // g_gemm_v2 (debug build; 10 = the 128 x 128 streaming kernel v1s wherever legal, split-K partials included): 0 = v1 only, 1 = the rule below, 2 = the 256 x 128 tile wherever it is legal, 3 = the 256 x 256 tile wherever legal,
     // 4 = the ping-pong 256 x 256 kernel wherever legal, 5 = 256 x 128 / 4 waves / BK 32 / two workgroups per CU wherever legal
+    // v1s: launches of at most ~one 128 x 128 tile per CU (the prefill's q|k|v projection, the tower's GEMMs at B = 1): three K tiles in flight
+    if (out_dtype == FVHD_BF16 && epi >= EPI_NONE && epi <= EPI_SWIGLU && take_gemm128s(M, N, K, (long)(M / 128) * (N / 128)))
+        return (int)dispatch_gemm128s(st, a, w, bias, ls, r, out, M, N, K, epi);
     if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128) {
         const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
 #ifdef FVHD_DEBUG_KNOBS

@@ -95,6 +95,12 @@ def test_gemm_identity_asymmetric():
     (4096, 4096, 192, _lib.EPI_BIAS_LS_RESID),  # ... 3 K tiles, layer scale + residual
     (8192, 2304, 768, _lib.EPI_NONE),           # ... qkv of stage 4 at B = 8
     (16384, 512, 256, _lib.EPI_BIAS),           # ... narrow N
+    (1024, 768, 768, _lib.EPI_BIAS_LS_RESID),   # 128 x 128 streaming kernel (v1s: <= 224 tiles, M % 128 == 0): stage-3 proj at B = 1, 12 K tiles
+    (256, 4608, 1536, _lib.EPI_NONE),           # ... stage-4 qkv at B = 1
+    (2304, 1152, 896, _lib.EPI_BIAS),           # ... the prefill's q|k|v projection
+    (128, 128, 128, _lib.EPI_BIAS_GELU),        # ... two K tiles: prologue only
+    (384, 256, 192, _lib.EPI_BIAS_GELU),        # ... three K tiles (ring not yet full)
+    (640, 384, 320, _lib.EPI_BIAS_LS_RESID),    # ... five K tiles (the ring wraps once)
 ])
 def test_gemm_epilogues(M, N, K, epi):
     A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
@@ -136,7 +142,7 @@ def test_gemm_inplace_residual_and_f32_out():
     _close(got16, _bf(A).float() @ _bf(W).float().t() + bias, rtol=2e-3, atol_rms=2e-3, what="gemm f16 out")
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 384, 1536), (1024, 768, 3072), (256, 1536, 6144), (1024, 768, 768), (300, 1536, 1536), (2048, 1536, 6144)])
+@pytest.mark.parametrize("M,N,K", [(4096, 384, 2048), (1024, 768, 3072), (256, 1536, 6144), (1024, 768, 2304), (300, 1536, 2560), (2048, 1536, 6144)])
 def test_gemm_split_k_residual(M, N, K):
     """fc2 / proj at small batches: the K of a GEMM with few output tiles is split over workgroups (fp32 partials, ordered reduce with the
     bias + layer-scale + residual epilogue).  Checked against the fp32 reference like the plain GEMM, and against the plain GEMM itself."""

@@ -227,7 +227,9 @@ def bench_gemmsmall():
                   ("s4 qkv", B * 256, 4608, 1536, 0), ("s4 fc1", B * 256, 6144, 1536, 2), ("s4 fc2", B * 256, 1536, 6144, 3)]
         if B == 1:
             shapes = [("s1 fc1", 16384, 768, 192, 2), ("s1 fc2", 16384, 192, 768, 3), ("s2 fc1", 4096, 1536, 384, 2), ("s2 fc2", 4096, 384, 1536, 3)] + shapes
-        for v2, nm in ((0, "v1"), (2, "256x128"), (3, "256x256"), (1, "default")):
+        shapes += [("llm qkv", 2304, 1152, 896, 1), ("llm oprj", 2304, 896, 896, 4), ("llm gtup", 2304, 9728, 896, 5), ("llm down", 2304, 896, 4864, 4)] if B == 8 else \
+                  [("llm qkv", 512, 1152, 896, 1), ("llm oprj", 512, 896, 896, 4), ("llm gtup", 512, 9728, 896, 5), ("llm down", 512, 896, 4864, 4)]
+        for v2, nm in ((0, "v1"), (10, "v1s"), (2, "256x128"), (3, "256x256"), (1, "default")):
             raw.fvhd_debug_set_gemm_v2(v2)
             print(f"--- B = {B}, gemm: {nm}")
             for name, M, N, K, epi in shapes:
@@ -237,6 +239,43 @@ def bench_gemmsmall():
                 out = torch.randn(M, N).to(DEV, torch.bfloat16)
                 t = timeit(lambda: _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(out), p(out), M, N, K, epi, 2)))
                 print(f"gemm {name:8s} M={M:6d} N={N:5d} K={K:5d} epi={epi}: {t*1e6:8.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF/s")
+    # split-K partial GEMMs + reduce (the prefill's o_proj / down_proj, the tower's fc2 at B = 1): v1 vs v1s slices
+    for v2, nm in ((0, "v1"), (10, "v1s")):
+        raw.fvhd_debug_set_gemm_v2(v2)
+        print(f"--- split-K, slices on {nm}")
+        for name, M, N, K, sp in (("llm o_proj", 2304, 896, 896, 2), ("llm down", 2304, 896, 4864, 4), ("s2 fc2 B1", 4096, 384, 1536, 4), ("s3 fc2 B1", 1024, 768, 3072, 8),
+                                  ("s4 fc2 B1", 256, 1536, 6144, 16), ("s4 fc2 B8", 2048, 1536, 6144, 2)):
+            A = torch.randn(M, K).to(DEV, torch.bfloat16)
+            W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
+            out = torch.randn(M, N).to(DEV, torch.bfloat16)
+            part = torch.empty(sp * M * N, device=DEV, dtype=torch.float32)
+            t = timeit(lambda: _lib.check(lib.fvhd_op_gemm_splitk(stream(), p(A), p(W), p(out), p(out), p(part), M, N, K, sp)))
+            print(f"split-K {name:10s} M={M:6d} N={N:5d} K={K:5d} / {sp:2d}: {t*1e6:8.1f} us")
+    # identical bits: v1 vs v1s, plain and split
+    for name, M, N, K, epi in (("proj-like", 1024, 768, 768, 3), ("qkv-like", 256, 4608, 1536, 0), ("llm qkv", 2304, 1152, 896, 1), ("swiglu", 512, 1024, 256, 5),
+                               ("one K tile", 128, 128, 128, 2), ("three K tiles", 384, 256, 192, 2)):
+        A = torch.randn(M, K).to(DEV, torch.bfloat16)
+        W = (torch.randn(N, K) * K ** -0.5).to(DEV, torch.bfloat16)
+        bias, ls = torch.randn(N, device=DEV), torch.rand(N, device=DEV)
+        res = torch.randn(M, N).to(DEV, torch.bfloat16)
+        outs = []
+        for v2 in (0, 10):
+            raw.fvhd_debug_set_gemm_v2(v2)
+            out = res.clone() if epi != 5 else torch.zeros(M, N // 2, device=DEV, dtype=torch.bfloat16)
+            _lib.check(lib.fvhd_op_gemm(stream(), p(A), p(W), p(bias), p(ls), p(res), p(out), M, N, K, epi, 2))
+            torch.cuda.synchronize()
+            outs.append(out.float())
+        parts = []
+        for v2 in (0, 10):
+            raw.fvhd_debug_set_gemm_v2(v2)
+            o2 = res.clone()
+            part = torch.zeros(2 * M * N, device=DEV, dtype=torch.float32)
+            if K % 128 == 0:
+                _lib.check(lib.fvhd_op_gemm_splitk(stream(), p(A), p(W), p(res), p(o2), p(part), M, N, K, 2))
+            torch.cuda.synchronize()
+            parts.append((o2.float(), part.clone()))
+        print(f"v1 vs v1s {name}: plain equal {bool(torch.equal(outs[0], outs[1]))} (max diff {float((outs[0] - outs[1]).abs().max()):.3g}), "
+              f"split-K equal {bool(torch.equal(parts[0][0], parts[1][0]) and torch.equal(parts[0][1], parts[1][1]))}")
     raw.fvhd_debug_set_gemm_v2(1)
 
 
