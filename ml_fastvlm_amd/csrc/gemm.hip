@@ -647,7 +647,7 @@ static hipError_t dispatch_gemm128s(hipStream_t st, const bf16* a, const bf16* w
 // (v1 then has 2-4 workgroups per CU covering each other's latency: stage-2 fc1 at B = 1, 384 tiles, 16.1 -> 21.0), and behind v1 for the
 // slices of a split-K launch with 250-500 workgroups (llm down / 4: 39.7 -> 43.0)
 #ifndef FVHD_GEMM128S_MAX_TILES
-#define FVHD_GEMM128S_MAX_TILES 224        // workgroups of one launch up to which v1s is taken (0 = never)
+#define FVHD_GEMM128S_MAX_TILES 256        // workgroups of one launch up to which v1s is taken (0 = never): one round of one workgroup per CU
 #endif
 static bool take_gemm128s(int M, int N, int K, long workgroups)
 {

@@ -92,7 +92,7 @@ struct fvhd_llm {
     int ws_rows = 0, ws_batch = 0, ws_pos = 0;
     char *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *last = nullptr, *lastn = nullptr;
     float *rope = nullptr, *part = nullptr;
-    int down_splits = 1, o_splits = 2, qkv_splits = 0, fuse_norm = 1;     // FVHD_LLM_SPLITK / FVHD_LLM_OSPLIT (max. split of o_proj, 0 = never) / FVHD_LLM_FUSENORM
+    int down_splits = kMaxSplits, o_splits = 2, qkv_splits = 0, fuse_norm = 1;     // FVHD_LLM_SPLITK / FVHD_LLM_OSPLIT (largest split of down_proj / o_proj, 0 = never) / FVHD_LLM_QKVSPLIT / FVHD_LLM_FUSENORM
     int max_pos = 0;                       // fvhd_llm_set_max_positions (config.max_position_embeddings): rows of the rotary table
     // A prefill that ran while its stream was being captured put this workspace's pointers into the CALLER's graph.  Such a workspace is
     // never freed when a later call needs a bigger one: it is retired (kept until fvhd_llm_destroy), so the captured graph keeps
@@ -408,14 +408,18 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
     // 0.5 B prefill shape (B = 8 x 285 tokens).  The reduce of a split GEMM also applies the RMSNorm the next operation starts with
     // (splitk_reduce_norm_kernel, bit-identical to the separate launch): input_layernorm of layer l + 1 behind down_proj of layer l, and -
     // when o_proj is split too (FVHD_LLM_OSPLIT) - post_attention_layernorm behind o_proj
+    // the largest split that still fits ONE round of the streaming 128 x 128 kernel (<= 256 workgroups: gemm.hip v1s) - else, as in round 3, the
+    // largest within two v1 workgroups per CU.  0.5 B at B = 8 (126 tiles): down_proj in TWO slices of 38 K steps on v1s instead of four of
+    // 19 on v1, 33 -> 16 MB of partials: prefill 3.92 -> 3.77 ms (profiles/r04_ttft_down_split.log)
     auto pick_splits = [&](int N, int K, int max_sp) {
         const long tiles = (long)(Mp / 128) * (N / 128);
         if (N % 128 == 0)
-            for (int sp = kMaxSplits; sp > 1; sp >>= 1)
-                if (sp <= max_sp && tiles * sp <= 512 && K % (64 * sp) == 0) return sp;
+            for (long cap = 256; cap <= 512; cap += 256)
+                for (int sp = kMaxSplits; sp > 1; sp >>= 1)
+                    if (sp <= max_sp && tiles * sp <= cap && K % (64 * sp) == 0) return sp;
         return 1;
     };
-    const int down_sp = pick_splits(H, I, c->down_splits > 0 ? kMaxSplits : 1), o_sp = pick_splits(H, nh * hd, c->o_splits);
+    const int down_sp = pick_splits(H, I, c->down_splits), o_sp = pick_splits(H, nh * hd, c->o_splits);
     // q|k|v projection: split in two, the reduce applies bias + rotary embedding + the KV-cache copies (splitk_bias_rope_kernel)
     const int qkv_sp = pick_splits(c->qkvw, H, std::min(c->qkv_splits, 2));
     bool xn_ready = false;                      // c->xn already holds input_layernorm(c->h) of the coming layer

@@ -95,7 +95,7 @@ def test_gemm_identity_asymmetric():
     (4096, 4096, 192, _lib.EPI_BIAS_LS_RESID),  # ... 3 K tiles, layer scale + residual
     (8192, 2304, 768, _lib.EPI_NONE),           # ... qkv of stage 4 at B = 8
     (16384, 512, 256, _lib.EPI_BIAS),           # ... narrow N
-    (1024, 768, 768, _lib.EPI_BIAS_LS_RESID),   # 128 x 128 streaming kernel (v1s: <= 224 tiles, M % 128 == 0): stage-3 proj at B = 1, 12 K tiles
+    (1024, 768, 768, _lib.EPI_BIAS_LS_RESID),   # 128 x 128 streaming kernel (v1s: <= 256 tiles, M % 128 == 0): stage-3 proj at B = 1, 12 K tiles
     (256, 4608, 1536, _lib.EPI_NONE),           # ... stage-4 qkv at B = 1
     (2304, 1152, 896, _lib.EPI_BIAS),           # ... the prefill's q|k|v projection
     (128, 128, 128, _lib.EPI_BIAS_GELU),        # ... two K tiles: prologue only
