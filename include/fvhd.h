@@ -42,6 +42,12 @@ typedef void* fvhd_stream_t; /* hipStream_t */
 #define FVHD_EPI_BIAS_GELU 2     /* out = gelu(A.W^T + b)                         (fc1, 1x1 convs, projector Linear #1) */
 #define FVHD_EPI_BIAS_LS_RESID 3 /* out = resid + ls * (A.W^T + b)                (fc2 / proj + layer scale + skip) */
 
+/* ABI version: major * 100 + minor.  A caller built against this header compares fvhd_version() with FVHD_VERSION before anything else
+ * (ml_fastvlm_amd/_lib.py does): the major part changes whenever an exported signature or the meaning of an argument changes.
+ * 100 = rounds 1-3; round 4 changed signatures under the same number (fvhd_op_stem_fused + w2 / b2, fvhd_op_ffn_fused / fvhd_ffn_pack +
+ * precision, fvhd_op_rope + rope_theta) - a mistake this number corrects; 500 = round 5 (adds the range guard, fvhd_op_dw7_amax,
+ * fvhd_llm_* stream contract; no signature of 4xx changed). */
+#define FVHD_VERSION 500
 int fvhd_version(void);
 const char* fvhd_last_error(void);
 
@@ -98,7 +104,8 @@ int fvhd_encode_images(fvhd_ctx* ctx, const void* images, int img_dtype, int bat
  * operand (FVHD_FFN_BF16: no range limit, ~3-7 % slower); both are compiled in and both weight images are packed, so the choice is a
  * per-block run-time switch:
  *   fvhd_set_ffn_precision / fvhd_get_ffn_precision  - by step index (fvhd_step_info); get returns -1 for a step without a fused ConvFFN.
- *     A block whose |4 * fc2.weight| would overflow f16 starts as FVHD_FFN_BF16.
+ *     A block whose |4 * fc2.weight| would overflow f16, whose largest |fc2.weight| is below 2^-10 (f16(4 W2) would sink into the f16
+ *     subnormals) or whose fc1 biases alone exceed 2^17 (range guard, below) starts as FVHD_FFN_BF16.
  *   fvhd_audit_ranges - one eager pass over `images` (a calibration batch of the deployment's real inputs) that also materialises every
  *     ConvFFN's fc1 output and reduces it to max |.|: max_abs_out[fvhd_num_steps] (0 for steps without a ConvFFN; Inf / NaN if the fc1
  *     output itself overflowed) and, when switch_above > 0, switches every fused block whose maximum exceeds it (or is not finite) to
@@ -110,6 +117,29 @@ int fvhd_set_ffn_precision(fvhd_ctx* ctx, int step, int precision);
 int fvhd_get_ffn_precision(const fvhd_ctx* ctx, int step);
 int fvhd_audit_ranges(fvhd_ctx* ctx, const void* images, int img_dtype, int batch, float switch_above, float* max_abs_out,
                       int* n_switched, fvhd_stream_t stream);
+
+/* ---- range guard (round 5): the half-precision form is never run outside its proven range twice ------
+ * An audit says nothing about an image hotter than the calibration batch.  The guard is always on and costs nothing measurable: the
+ * depthwise 7x7 (+BN) that produces a fused block's input A reduces max |A| on the fly (free issue slots of the matrix-core kernel),
+ * and since |fc1 out_j| <= L1(W1 row j) * max|A| + |b1_j|, a block is PROVABLY inside the half-precision range while
+ *     max|A| <= limit = (2^17 - max_j |b1_j|) / max_j L1(W1 row j)          (2^17 = half of the 262 016 saturation point)
+ * holds (fvhd_range_guard_limit; computed from the packed weights at fvhd_finalize_weights; a block whose biases alone exceed 2^17
+ * starts as FVHD_FFN_BF16).  Every fvhd_encode* call zeroes the per-step maxima, its kernels reduce into them, and the array is read
+ * back asynchronously (pinned host memory + an event; no synchronisation).  The NEXT fvhd_encode* call - or fvhd_range_guard_poll -
+ * compares the finished read-backs with the limits: a block over its limit is switched to FVHD_FFN_BF16 for every later call and reported.
+ * The bound is sufficient, not necessary: it can move a block that would not have saturated (costing that block 3-7 %), never the other
+ * way round.  What it cannot do is repair the one batch that crossed the limit - that call's output used the half form; callers that need
+ * the guarantee per batch poll with wait = 1 after the call and re-encode when a step is reported (the Python tower does exactly that
+ * when mm_vision_range_guard = "strict").  Inactive while the caller's stream is being captured (an event inside a graph cannot be
+ * polled): graph-capturing callers calibrate with fvhd_audit_ranges first.
+ *   fvhd_set_range_guard(ctx, 0 / 1)   - default 1 (environment: FVHD_RANGE_GUARD=0).
+ *   fvhd_range_guard_limit             - the limit on max|A| of a fused step (INFINITY if fc1.weight is all zero, < 0 if never in range).
+ *   fvhd_range_guard_poll              - consume the finished read-backs (wait != 0: all outstanding ones, synchronising on their events);
+ *                                        steps_out / amax_out [max_out] receive the steps switched since the last poll and the max|A| that
+ *                                        did it, *n_out how many. */
+int fvhd_set_range_guard(fvhd_ctx* ctx, int on);
+int fvhd_range_guard_limit(const fvhd_ctx* ctx, int step, float* limit_out);
+int fvhd_range_guard_poll(fvhd_ctx* ctx, int wait, int* steps_out, float* amax_out, int max_out, int* n_out);
 
 /* geometry helpers (mobileclip_encoder.py:106-116) */
 int fvhd_num_tokens(const fvhd_ctx* ctx);   /* (R/64)^2 */
@@ -176,6 +206,13 @@ int fvhd_op_dwconv(fvhd_stream_t stream, const void* x, void* y, const float* w,
  * the chip (or always, under fvhd_set_batch_invariant).  Same arguments as fvhd_op_dwconv(K = 7, stride 1, mult 1, no GELU);
  * needs C % 64 == 0 or C % 96 == 0 and W >= 16, anything else is an error. */
 int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
+/* The same convolution with the range guard's reduction (round 5): amax_bits (device, 4 bytes, zeroed by the caller) receives max |y| - over
+ * everything the launch stores (VALU kernel, mfma = 0) or over the stored rows and the columns of the kernel's 64-px strips (matrix-core kernel,
+ * mfma = 1: for W % 64 != 0 a superset of the image, computed from the zero padding) - as the fp32 bit pattern of a non-negative number
+ * (combined with atomicMax: unsigned order = numeric order), taken from the fp32 accumulators before the rounding to bf16.  mfma = 0 is an error
+ * for shapes the dispatcher gives to the matrix-core kernel, mfma = 1 for shapes that kernel does not take. */
+int fvhd_op_dw7_amax(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, int mfma,
+                     void* amax_bits);
 /* out[M,N] = epi(A[M,K] . Wt[N,K]^T): A, Wt, resid bf16; bias, ls fp32 [N]; K % 32 == 0, N % 16 == 0.  out_dtype other than bf16 only with
  * FVHD_EPI_BIAS (f16 / f32) and FVHD_EPI_NONE (f32: lm_head logits); FVHD_EPI_SWIGLU writes [M, N/2]. */
 int fvhd_op_gemm(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, const float* ls,

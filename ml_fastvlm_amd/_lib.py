@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FVHD_LIB: another build of the same ABI (the ablation library of `python -m ml_fastvlm_amd.build` with FVHD_FFN_ABLATE=1)
 LIB_PATH = os.environ.get("FVHD_LIB") or os.path.join(_HERE, "libfvhd.so")
 
+ABI_VERSION = 500               # FVHD_VERSION of the include/fvhd.h this stub was written against (major = ABI_VERSION // 100)
 F32, F16, BF16 = 0, 1, 2
 FFN_HALF, FFN_BF16 = 0, 1        # precision of the fused ConvFFN's hidden activation (include/fvhd.h)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_LS_RESID, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3, 4, 5
@@ -65,6 +66,10 @@ def _declare(lib) -> None:
         "fvhd_set_ffn_precision": (ci, [vp, ci, ci]),
         "fvhd_get_ffn_precision": (ci, [vp, ci]),
         "fvhd_audit_ranges": (ci, [vp, vp, ci, ci, cf, C.POINTER(C.c_float), C.POINTER(ci), vp]),
+        "fvhd_set_range_guard": (ci, [vp, ci]),
+        "fvhd_range_guard_limit": (ci, [vp, ci, C.POINTER(C.c_float)]),
+        "fvhd_range_guard_poll": (ci, [vp, ci, C.POINTER(ci), C.POINTER(C.c_float), ci, C.POINTER(ci)]),
+        "fvhd_op_dw7_amax": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
         "fvhd_op_preprocess": (ci, [vp, vp, ci, ci, C.c_int64, ci, ci, C.c_uint32, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp, ci, vp, ci]),
         "fvhd_op_splice": (ci, [vp] * 12 + [ci, ci, ci, ci, C.c_int64, C.c_int64, ci, ci]),
         "fvhd_llm_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci, ci, cf, cf]),
@@ -102,6 +107,10 @@ def load():
                 "(hipcc, gfx950). There is no CPU fallback for this path.")
         lib = C.CDLL(LIB_PATH)
         _declare(lib)
+        got = lib.fvhd_version()
+        if got // 100 != ABI_VERSION // 100 or got < ABI_VERSION:
+            raise FvhdError(f"{LIB_PATH} reports ABI version {got}, this binding was written for {ABI_VERSION} (include/fvhd.h FVHD_VERSION): "
+                            "rebuild the library (`python -m ml_fastvlm_amd.build`) - argument lists differ between major versions")
         _lib = lib
     return _lib
 
@@ -160,6 +169,24 @@ class Context:
         t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
         shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
         check(load().fvhd_set_tensor(self._h, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()), f"fvhd_set_tensor({key})")
+
+    def set_tensors(self, tensors) -> None:
+        """All floating-point tensors of a state dict in ONE device-to-host transfer (round 5: the per-tensor `.to("cpu")` of `set_tensor`
+        was 629 small synchronising copies on every `.to()` / re-pack of the tower): same-dtype tensors are concatenated on their device,
+        cast to fp32 there, copied once, and handed to `fvhd_set_tensor` as views of that one host buffer (the library copies them)."""
+        import torch
+        items = [(k, v.detach()) for k, v in tensors.items() if v.is_floating_point()]
+        groups = {}
+        for k, v in items:
+            groups.setdefault((v.device, v.dtype), []).append((k, v))
+        for (_dev, _dt), grp in groups.items():
+            flat = torch.cat([v.reshape(-1) for _, v in grp]).to(dtype=torch.float32).cpu().contiguous()
+            off = 0
+            for k, v in grp:
+                n = v.numel()
+                shape = (C.c_int64 * max(1, v.dim()))(*v.shape)
+                check(load().fvhd_set_tensor(self._h, k.encode(), C.c_void_p(flat.data_ptr() + 4 * off), shape, v.dim()), f"fvhd_set_tensor({k})")
+                off += n
 
     def finalize(self) -> None:
         check(load().fvhd_finalize_weights(self._h), "fvhd_finalize_weights")
@@ -227,6 +254,23 @@ class Context:
         check(load().fvhd_audit_ranges(self._h, ptr(images), dtype_code(images.dtype), images.shape[0], float(switch_above), out, C.byref(sw),
                                        stream_ptr(images.device)), "fvhd_audit_ranges")
         return [out[i] for i in range(n)], sw.value
+
+    def set_range_guard(self, on: bool) -> None:
+        """the always-on range guard of the half-precision fused ConvFFN (include/fvhd.h "range guard"); default on"""
+        check(load().fvhd_set_range_guard(self._h, int(bool(on))), "fvhd_set_range_guard")
+
+    def range_guard_limit(self, step: int) -> float:
+        """largest max |A| for which the fused block of `step` is provably inside the half-precision range"""
+        out = C.c_float(0.0)
+        check(load().fvhd_range_guard_limit(self._h, int(step), C.byref(out)), "fvhd_range_guard_limit")
+        return out.value
+
+    def range_guard_poll(self, wait: bool = False):
+        """-> [(step, max |A|)] of the blocks the guard has moved to the bf16-operand form since the last poll"""
+        cap = 64
+        steps, amax, n = (C.c_int * cap)(), (C.c_float * cap)(), C.c_int(0)
+        check(load().fvhd_range_guard_poll(self._h, int(bool(wait)), steps, amax, cap, C.byref(n)), "fvhd_range_guard_poll")
+        return [(steps[i], amax[i]) for i in range(n.value)]
 
     def set_graph(self, on: bool) -> None:
         """replay the interior steps as one hipGraph per batch size (launch-bound small batches)."""

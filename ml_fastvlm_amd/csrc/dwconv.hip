@@ -54,8 +54,10 @@ struct DwTile {
 template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, int PREF = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void dwconv_tiled_kernel(
     const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
-    int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int ntiles, int dbg_mode)
+    int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int ntiles, int dbg_mode, unsigned* amax)
 {
+    // amax (round 5, may be null): max |output| over everything this launch stores, as the fp32 bit pattern of a non-negative number
+    // (atomicMax on unsigned = numeric max) - the range guard of the half-precision fused ConvFFN reads it (fvhd_api.hip: run_ffn)
     using T = DwTile<K, S, MULT, ACT, CS, OW4>;
     constexpr int PAD = T::PAD, CSI = T::CSI, LPP = T::LPP, LPI = T::LPI, OWT = T::OWT, TW = T::TW, TH = T::TH;
     constexpr int IW = T::IW, IWP = T::IWP, NIN = T::NIN, CI = T::CI, NLD = T::NLD, IH_ = T::IH;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // at the top of the tile and the other resident workgroups cover their latency; PREF 2: LDS-DMA into the other of
     // two LDS tile buffers during the tap loop (one barrier per tile)
     unsigned zm_cur = 0, cur = 0;
+    float amx = 0.f;
     if (PREF == 1 && L0 < ntiles) issue_loads(L0);
     if (DMA && L0 < ntiles && dbg_mode != 2) zm_cur = issue_dma(L0, lds_tile0);
     for (int t = L0; t < ntiles; t += G) {
@@ -243,9 +246,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rr[c] = ACT ? gelu_erf(acc[o][c]) : acc[o][c];
                 *(bf16x8*)(yo + (size_t)o * Cout) = f32_to_bf8(rr);
+                if (amax) {                                     // wave-uniform; v_max3_f32 with |.| modifiers: 4 VALU per 8 outputs
+#pragma unroll
+                    for (int c = 0; c < 8; c += 2) amx = __builtin_fmaxf(__builtin_fmaxf(amx, __builtin_fabsf(rr[c])), __builtin_fabsf(rr[c + 1]));
+                }
             }
         }
         if constexpr (!DMA) __syncthreads();   // every wave is done reading the LDS tile before the next one overwrites it
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
+        if ((tid & 63) == 0 && amx > 0.f) atomicMax(amax, __float_as_uint(amx));
     }
 }
 
@@ -266,7 +278,7 @@ static constexpr int g_dw7_cfg = 1, g_dw3_cfg = -1, g_dw_mode = 0;
 
 template <int K, int S, int MULT, bool ACT, int CS, bool OW4 = false, int WPE = 2, int PREF = 1>
 static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const float* w, const float* bias,
-                                  int B, int H, int W, int Cin)
+                                  int B, int H, int W, int Cin, unsigned* amax = nullptr)
 {
     using T = DwTile<K, S, MULT, ACT, CS, OW4>;
     const int OH = (H + 2 * T::PAD - K) / S + 1, OW = (W + 2 * T::PAD - K) / S + 1;
@@ -291,18 +303,19 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
     if (G <= 0) G = q;
     if (ntiles <= 3 * G) G = ((ntiles + nslices - 1) / nslices) * nslices;   // few rounds: one tile per workgroup (dynamic balance beats persistence)
     hipLaunchKernelGGL((dwconv_tiled_kernel<K, S, MULT, ACT, CS, OW4, WPE, PREF>), dim3(G), dim3(256), SHMEM, st, x, y, w, bias,
-                       B, H, W, Cin, OH, OW, tiles_x, tiles_y, nslices, ntiles, g_dw_mode);
+                       B, H, W, Cin, OH, OW, tiles_x, tiles_y, nslices, ntiles, g_dw_mode, amax);
     return hipGetLastError();
 }
 
 // x [B,H,W,Cin] bf16 -> y [B,OH,OW,Cin*mult] bf16; w fp32 [K*K][Cout]; bias fp32 [Cout] or null.
 extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force);
-extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
+extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax);
 
 // batch_invariant != 0: the kernel choice may depend on the SHAPE of one image only, never on B (bit-identical rows whatever the
 // batch they travel in); 0: the fastest kernel for this B (the VALU dw7x7 below the matrix-core kernel's fill threshold)
+// amax (may be null; honoured by the 7x7 stride-1 kernels only - the ConvFFN's depthwise conv): see dwconv_tiled_kernel
 extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const float* w, const float* bias,
-                                  int B, int H, int W, int Cin, int K, int stride, int mult, int gelu, int batch_invariant)
+                                  int B, int H, int W, int Cin, int K, int stride, int mult, int gelu, int batch_invariant, unsigned* amax)
 {
     const bf16* xi = (const bf16*)x;
     bf16* yo = (bf16*)y;
@@ -316,7 +329,7 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // come in whole 128-B lines: 109 / 60 us at C = 192 / 384 (B = 32, 1024^2 input) against 246 / 118 for the VALU kernel
     // below, which stays for C = 96, narrow maps and as the comparison path (debug build: fvhd_debug_set_dw7_cfg(0)).
     if (K == 7 && stride == 1 && mult == 1 && !gelu && g_dw7_cfg != 0 && fvhd_dw7_mfma_supported(B, H, W, Cin, batch_invariant || g_dw7_cfg == 5))
-        return fvhd_launch_dw7_mfma(st, x, y, w, bias, B, H, W, Cin);
+        return fvhd_launch_dw7_mfma(st, x, y, w, bias, B, H, W, Cin, amax);
     if (K == 7 && stride == 1 && mult == 1 && !gelu && c32) {
         // measured per channel count (tools/bench_ops.py dw7cfg, B = 32, us): config 4 = 32-channel slices / 4-pixel strips,
         // two LDS tile buffers filled by LDS-DMA during the tap loop, 2 waves per SIMD: 445 / 246 / 118 at C = 96 / 192 / 384
@@ -325,9 +338,9 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
         const int vcfg = (g_dw7_cfg == 0 || g_dw7_cfg == 5) ? 1 : g_dw7_cfg;
         const bool wide = c64 && (vcfg == 3 || (vcfg == 1 && Cin >= 1536));
         const bool dma = vcfg == 4 || (vcfg == 1 && Cin <= 384);
-        if (dma) return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 2, 2>(st, xi, yo, w, bias, B, H, W, Cin);
-        if (wide) return (int)launch_dw_tiled<7, 1, 1, false, 64, false, 2, 0>(st, xi, yo, w, bias, B, H, W, Cin);
-        return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 3, 0>(st, xi, yo, w, bias, B, H, W, Cin);
+        if (dma) return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 2, 2>(st, xi, yo, w, bias, B, H, W, Cin, amax);
+        if (wide) return (int)launch_dw_tiled<7, 1, 1, false, 64, false, 2, 0>(st, xi, yo, w, bias, B, H, W, Cin, amax);
+        return (int)launch_dw_tiled<7, 1, 1, false, 32, true, 3, 0>(st, xi, yo, w, bias, B, H, W, Cin, amax);
     }
     // RepMixer dw3x3: from C = 192 on the LDS-DMA double-buffered tiles with 64-channel slices (whole 128-B lines per pixel) win
     // over the register-prefetch tiles - 99.7 -> 87.0 / 42.1 -> 37.4 us at C = 192 / 384 (B = 32), 42.0 -> 37.4 / 26.5 -> 21.9 us for

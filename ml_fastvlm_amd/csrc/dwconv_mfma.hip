@@ -68,8 +68,12 @@ FVHD_DEV u16 f32_to_bf16_rne(float f) { unsigned u = __float_as_uint(f); u += 0x
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restrict__ x, u16* __restrict__ y, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, int H, int W, int C, int RC, int nstrip, int nchunk)
+                                                              const float* __restrict__ bias, int H, int W, int C, int RC, int nstrip, int nchunk,
+                                                              unsigned* amax)
 {
+    // amax (round 5, may be null): max |output| (fp32, before the rounding to bf16) over the rows this launch stores and the columns of its
+    // strips (for W % 64 != 0 that includes up to 63 columns right of the image, computed from the zero padding: a superset, never less than
+    // the image's own maximum), as the fp32 bit pattern of a non-negative number - the range guard of the half-precision fused ConvFFN
     using K = DwmCfg<NW>;
     constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = DWM_RS, P = DWM_P, OPX = K::OPX, RAWB = K::RAWB, OB = K::OB, TBY = K::TB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
             for (int e = 0; e < 8; ++e) tr_write1(v, 0, m, e);
     }
     int r = r_lo, slot = r_lo % RS, ob = 0, tb = 0;         // slot: raw slot of row r; ob: staging buffer of output row r - 3; tb: T buffer of row r
+    float amx = 0.f, cand = 0.f;                            // running max |output| of this lane / of the row being finished
     for (;;) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
@@ -291,6 +296,15 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                     stage_cvt(pk, acc[u]);
                 }
                 if (!(DWM_ABL & 2) && k >= 64 && k < 80) stage_write1(pk, ob, k - 64);
+                // max |.| of the finished row (its 16 accumulators: final since MFMA 59, pinned at k = 62), two v_max3_f32 per free slot;
+                // rows above the chunk (their slots hold partial sums and are never stored) do not count
+                if (k == 63) cand = 0.f;
+                if (k == 63 || (k >= 80 && k < 83)) {
+                    const int t = k == 63 ? 0 : k - 79;
+                    cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t][0])), __builtin_fabsf(acc[u][t][1]));
+                    cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t][2])), __builtin_fabsf(acc[u][t][3]));
+                }
+                if (k == 83) amx = (r - 3 >= ylo) ? __builtin_fmaxf(amx, cand) : amx;
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = nslot;
@@ -311,7 +325,13 @@ done:
         const int sl = (yo - r_lo + 3) % 7;
 #pragma unroll
         for (int s7 = 0; s7 < 7; ++s7)
-            if (s7 == sl) stage(acc[s7], ob);
+            if (s7 == sl) {
+                stage(acc[s7], ob);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) amx = __builtin_fmaxf(amx, __builtin_fabsf(acc[s7][t][i]));
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         u32x4 ov[2];
@@ -320,6 +340,11 @@ done:
         ob ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the LDS is released
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
+        if (lane == 0 && amx > 0.f) atomicMax(amax, __float_as_uint(amx));
+    }
 }
 
 }  // namespace
@@ -349,7 +374,7 @@ static int dwm_rows_per_chunk(int B, int H, int W, int C)
 }
 
 template <int NW>
-static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)
+static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax)
 {
     static bool attr_set[64] = {};                           // per device (one process may drive several contexts)
     int dev = 0;
@@ -363,7 +388,7 @@ static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, co
     const int nstrip = (W + 63) / 64, nchunk = (H + RC - 1) / RC;
     const long long grid = (long long)B * (C / (16 * NW)) * nstrip * nchunk;
     if (grid <= 0 || grid > 0x7fffffffll) return (int)hipErrorInvalidValue;
-    dw7_mfma_kernel<NW><<<(int)grid, 64 * NW, DwmCfg<NW>::LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk);
+    dw7_mfma_kernel<NW><<<(int)grid, 64 * NW, DwmCfg<NW>::LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk, amax);
     return (int)hipGetLastError();
 }
 
@@ -378,8 +403,8 @@ extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force)
 }
 
 // x, y [B, H, W, C] bf16 (NHWC); w fp32 [49][C]; bias fp32 [C] or null
-extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)
+extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax)
 {
     if (!fvhd_dw7_mfma_supported(B, H, W, C, 1)) return (int)hipErrorInvalidValue;
-    return C % 64 == 0 ? launch_dwm<4>(st, x, y, w, bias, B, H, W, C) : launch_dwm<6>(st, x, y, w, bias, B, H, W, C);
+    return C % 64 == 0 ? launch_dwm<4>(st, x, y, w, bias, B, H, W, C, amax) : launch_dwm<6>(st, x, y, w, bias, B, H, W, C, amax);
 }

@@ -24,13 +24,15 @@
 //   * block ids are remapped so each XCD's private L2 sees a contiguous range of the tile order, and the order walks
 //     8 x 8 super-tiles (see the kernel): every A / W panel fetched from HBM feeds 8 resident tiles.
 #include "fvhd_common.h"
+#include "gemm_layout.h"
 
 #define EPI_NONE 0
 #define EPI_BIAS 1
 #define EPI_BIAS_GELU 2
 #define EPI_BIAS_LS_RESID 3
 #define EPI_RESID 4        // out = resid + A.W^T                        (Qwen2 o_proj / down_proj + the decoder layer's skip)
-#define EPI_SWIGLU 5       // out[m][j] = silu(acc[m][2j]) * acc[m][2j+1], out is [M, N/2]: W rows interleaved gate_j, up_j (Qwen2MLP)
+static_assert(FVHD_EPI_SWIGLU_ID == 5 && FVHD_ODT_BF16_ID == FVHD_BF16, "gemm_layout.h ids");
+#define EPI_SWIGLU 5       // (= FVHD_EPI_SWIGLU_ID of gemm_layout.h)  out[m][j] = silu(acc[m][2j]) * acc[m][2j+1], out is [M, N/2]: W rows interleaved gate_j, up_j (Qwen2MLP)
 
 template <int BK>
 FVHD_DEV int lds_off(int row, int ks)
@@ -39,43 +41,111 @@ FVHD_DEV int lds_off(int row, int ks)
     else return row * 64 + ((ks ^ ((0 - (row >> 2)) & 3)) << 4);
 }
 
-// ---- epilogue of one wave's (16 MF) x (16 NF) block: lane holds out[m][n .. n+3], m = mw + 16 i + lr, n = nw + 16 j + 4 g
+// ---- which W row an LDS row of the W tile holds (round 5: whole 16-B stores in 64-B segments, for free) -------------------------
+// The MFMA is issued "swapped" (D = Wfrag x Afrag^T): lane (lr, g) of fragment j ends up with D rows 4 g .. 4 g + 3 = the W rows that
+// lanes 4 g .. 4 g + 3 fed.  With LDS row p holding W row p (rounds 1-4) those are the columns n0 + 16 j + 4 g .. + 3: an 8-B store per
+// lane, 16 rows x 32 B per wave-instruction - and rocprofv3 counted 1.5-1.7x the algorithmic bytes written by every GEMM class
+// (profiles/r04_pmc_summary.md; the fused ConvFFN, whose stores are whole lines, writes 1.00x).  Nothing forces LDS row p to hold W row p:
+// the tile is filled row by row (LDS-DMA pieces of 8 rows / register staging), so the fill permutes the rows inside every block of 16 GRP
+//     LDS row 16 GRP b + 16 jl + 4 q + t   <-   W row 16 GRP b + 4 GRP q + 4 jl + t          (jl < GRP, q < 4, t < 4)
+// and lane (lr, g) then holds, over the GRP fragments j = GRP jb + jl, the 4 GRP CONSECUTIVE columns n0 + 16 GRP jb + 4 GRP g ..: one 16-B
+// store (and one 16-B residual load) per lane, 16 rows x 64 B per wave-instruction.  Same products in the same K order per output
+// element: identical bits.  GRP = 2 for bf16 outputs (8 columns = 16 B), 4 for SwiGLU (16 gate / up columns -> 8 outputs = 16 B; 4-B stores
+// before), 1 (identity) for fp32 / f16 outputs (4 columns are 16 B already) and for the 96-wide tile (3 fragments per wave).
+// (EpiGrp, wrow_of_lds_row, wpiece_row, wpiece_lane_row, epi_col: gemm_layout.h - shared with the CPU test of the mapping)
+// ---- epilogue of one wave's (16 MF) x (16 NF) block.  GRP = 1: lane holds out[m][n .. n+3], m = mw + 16 i + lr, n = nw + 16 j + 4 g;
+// GRP = 2 / 4: out[m][n .. n + 4 GRP - 1], n = nw + 16 GRP jb + 4 GRP g, as acc[i][GRP jb .. GRP jb + GRP - 1]
 template <int MF, int NF, int EPI, int ODT>
 FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias, const float* __restrict__ ls, const bf16* resid, void* out,
                             int M, int N, int mw, int nw, int lr, int g)
 {
+    constexpr int GRP = EpiGrp<NF, EPI, ODT>::value;
+    if constexpr (GRP == 1) {
 #pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int n = nw + j * 16 + g * 4;
-        if (n >= N) continue;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, lv = f32x4{1.f, 1.f, 1.f, 1.f};
-        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_LS_RESID) bv = *(const f32x4*)(bias + n);
-        if constexpr (EPI == EPI_BIAS_LS_RESID) lv = *(const f32x4*)(ls + n);
+        for (int j = 0; j < NF; ++j) {
+            const int n = nw + j * 16 + g * 4;
+            if (n >= N) continue;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, lv = f32x4{1.f, 1.f, 1.f, 1.f};
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_LS_RESID) bv = *(const f32x4*)(bias + n);
+            if constexpr (EPI == EPI_BIAS_LS_RESID) lv = *(const f32x4*)(ls + n);
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = mw + i * 16 + lr;
-            if (m >= M) continue;
-            f32x4 v = acc[i][j] + bv;
-            if constexpr (EPI == EPI_SWIGLU) {
-                // the lane's 4 consecutive columns are (gate, up, gate, up) of hidden units n/2, n/2 + 1: silu(gate) * up, written
-                // to the [M, N/2] activation (4-B store)
-                static_assert(ODT == FVHD_BF16, "SwiGLU writes the bf16 activation");
-                const f32x2 r = {v[0] * sigmoidf_fast(v[0]) * v[1], v[2] * sigmoidf_fast(v[2]) * v[3]};
-                *(bf16x2*)((bf16*)out + (size_t)m * (N / 2) + n / 2) = __builtin_convertvector(r, bf16x2);
-                continue;
-            }
-            if constexpr (EPI == EPI_BIAS_GELU) {
+            for (int i = 0; i < MF; ++i) {
+                const int m = mw + i * 16 + lr;
+                if (m >= M) continue;
+                f32x4 v = acc[i][j] + bv;
+                if constexpr (EPI == EPI_SWIGLU) {
+                    // the lane's 4 consecutive columns are (gate, up, gate, up) of hidden units n/2, n/2 + 1: silu(gate) * up, written
+                    // to the [M, N/2] activation (4-B store)
+                    static_assert(ODT == FVHD_BF16, "SwiGLU writes the bf16 activation");
+                    const f32x2 r = {v[0] * sigmoidf_fast(v[0]) * v[1], v[2] * sigmoidf_fast(v[2]) * v[3]};
+                    *(bf16x2*)((bf16*)out + (size_t)m * (N / 2) + n / 2) = __builtin_convertvector(r, bf16x2);
+                    continue;
+                }
+                if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+                    for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+                }
+                const size_t o = (size_t)m * N + n;
+                if constexpr (EPI == EPI_BIAS_LS_RESID || EPI == EPI_RESID) {
+                    const f32x4 r = bf4_to_f32(*(const bf16x4*)(resid + o));
+                    v = r + lv * v;
+                }
+                if constexpr (ODT == FVHD_BF16) *(bf16x4*)((bf16*)out + o) = f32_to_bf4(v);
+                else if constexpr (ODT == FVHD_F16) *(f16x4*)((_Float16*)out + o) = __builtin_convertvector(v, f16x4);
+                else *(f32x4*)((float*)out + o) = v;
             }
-            const size_t o = (size_t)m * N + n;
-            if constexpr (EPI == EPI_BIAS_LS_RESID || EPI == EPI_RESID) {
-                const f32x4 r = bf4_to_f32(*(const bf16x4*)(resid + o));
-                v = r + lv * v;
+        }
+    } else {
+        static_assert(ODT == FVHD_BF16 && NF % GRP == 0, "grouped epilogue: bf16 outputs");
+#pragma unroll
+        for (int jb = 0; jb < NF / GRP; ++jb) {
+            const int n = nw + epi_col<GRP>(jb, g);
+            if (n >= N) continue;
+            f32x4 bv[GRP], lv[GRP];
+#pragma unroll
+            for (int c = 0; c < GRP; ++c) {
+                bv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                lv[c] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_LS_RESID) bv[c] = *(const f32x4*)(bias + n + 4 * c);
+                if constexpr (EPI == EPI_BIAS_LS_RESID) lv[c] = *(const f32x4*)(ls + n + 4 * c);
             }
-            if constexpr (ODT == FVHD_BF16) *(bf16x4*)((bf16*)out + o) = f32_to_bf4(v);
-            else if constexpr (ODT == FVHD_F16) *(f16x4*)((_Float16*)out + o) = __builtin_convertvector(v, f16x4);
-            else *(f32x4*)((float*)out + o) = v;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = mw + i * 16 + lr;
+                if (m >= M) continue;
+                f32x4 v[GRP];
+#pragma unroll
+                for (int c = 0; c < GRP; ++c) v[c] = acc[i][jb * GRP + c] + bv[c];
+                if constexpr (EPI == EPI_SWIGLU) {
+                    // 16 consecutive columns = (gate, up) of the 8 hidden units n/2 .. n/2 + 7: one 16-B store into the [M, N/2] activation
+                    static_assert(GRP == 4, "SwiGLU: four fragments per group");
+                    f32x8 r;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        r[2 * c] = v[c][0] * sigmoidf_fast(v[c][0]) * v[c][1];
+                        r[2 * c + 1] = v[c][2] * sigmoidf_fast(v[c][2]) * v[c][3];
+                    }
+                    *(bf16x8*)((bf16*)out + (size_t)m * (N / 2) + n / 2) = f32_to_bf8(r);
+                    continue;
+                } else {
+                    static_assert(EPI == EPI_SWIGLU || GRP == 2, "bf16 rows: two fragments per group");
+                    if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int c = 0; c < GRP; ++c)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[c][e] = gelu_erf(v[c][e]);
+                    }
+                    const size_t o = (size_t)m * N + n;
+                    if constexpr (EPI == EPI_BIAS_LS_RESID || EPI == EPI_RESID) {
+                        const bf16x8 rr = *(const bf16x8*)(resid + o);
+                        const f32x4 r0 = bf4_to_f32(__builtin_shufflevector(rr, rr, 0, 1, 2, 3)), r1 = bf4_to_f32(__builtin_shufflevector(rr, rr, 4, 5, 6, 7));
+                        v[0] = r0 + lv[0] * v[0];
+                        v[1] = r1 + lv[1] * v[1];
+                    }
+                    const bf16x4 b0 = f32_to_bf4(v[0]), b1 = f32_to_bf4(v[1]);
+                    *(bf16x8*)((bf16*)out + o) = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
         }
     }
 }
@@ -129,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 #pragma unroll
     for (int i = 0; i < W_CH; ++i) {
         const int idx = i * 256 + tid, row = min(idx / CPR, BN - 1), ks = idx % CPR;
-        const int gr = min(n0 + row, N - 1);
+        const int gr = min(n0 + wrow_of_lds_row<EpiGrp<NF, EPI, ODT>::value>(row), N - 1);     // LDS row `row` holds this W row (see EpiGrp)
         w_src[i] = Wt + (size_t)gr * ldk + ks * 8;
         w_dst[i] = (idx < BN * CPR) ? lds_off<BK>(row, ks) : -1;
     }
@@ -237,16 +307,20 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
 
     // per-lane global byte offsets of this wave's pieces: rows 8 p + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7); the swizzle
     // term depends on the piece's parity only, the row base of a piece goes into the scalar base
+    // W pieces: LDS rows 8 pi .. 8 pi + 7 hold the W rows wpiece_row(pi) + wpiece_lane_row(rip) (EpiGrp: the lane's output columns become
+    // consecutive); A pieces are plain
+    constexpr int GRP = EpiGrp<NF, EPI, ODT>::value;
+    static_assert(GRP == 1 || BK == 64, "the W row permutation is written for 8-row pieces");
     const int rip = lane / LPR;
     unsigned va[2], vw[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         const int sw = lds_swz<BK>(par * RPP + rip);
         va[par] = (unsigned)((rip * K + (((lane % LPR) ^ sw) * 8)) * 2);
-        vw[par] = va[par];
+        vw[par] = (unsigned)((wpiece_lane_row<GRP>(rip) * K + (((lane % LPR) ^ sw) * 8)) * 2);
     }
     const char* abase = (const char*)(A + (size_t)(m0 + wave * RPP * PA) * K);   // A pieces PA wave .. PA wave + PA - 1 = rows RPP PA wave ..
-    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * RPP * PW) * K);  // W pieces PW wave ..
+    const char* wbase = (const char*)(Wt + (size_t)n0 * K);
     const unsigned lds0 = lds_addr(lds2);
     auto issue = [&](int kt) {
         if constexpr (ABL == 1) return;
@@ -255,7 +329,11 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
 #pragma unroll
         for (int j = 0; j < PA; ++j) glds_piece(va[(wave * PA + j) & 1], abase + (size_t)j * RPP * K * 2 + ko, st + (wave * PA + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < PW; ++j) glds_piece(vw[(wave * PW + j) & 1], wbase + (size_t)j * RPP * K * 2 + ko, st + BM * BK * 2 + (wave * PW + j) * 1024);
+        for (int j = 0; j < PW; ++j) {
+            const int pi = wave * PW + j;                       // wave-uniform
+            const int wr = GRP == 1 ? pi * RPP : wpiece_row<GRP>(pi);
+            glds_piece(vw[pi & 1], wbase + (size_t)wr * K * 2 + ko, st + BM * BK * 2 + pi * 1024);
+        }
     };
 
     f32x4 acc[MF][NF];
@@ -335,13 +413,17 @@ __global__ __launch_bounds__(256, 1) void gemm128s_kernel(
     const int m0 = tm * BM, n0 = tn * 128;
 
     // lane l of a 1-KiB piece (8 rows x 128 B) fetches chunk (l & 7) ^ swizzle(row) of row l >> 3; the key depends on the piece's parity only
+    constexpr int GRP = EpiGrp<NF, EPI, ODT>::value;       // W rows permuted inside the tile: see EpiGrp
     const int rip = lane >> 3;
-    unsigned va[2];
+    unsigned va[2], vw[2];
 #pragma unroll
-    for (int par = 0; par < 2; ++par)
-        va[par] = (unsigned)((rip * ldk + (((lane & 7) ^ lds_swz<BK>(par * RPP + rip)) * 8)) * 2);
+    for (int par = 0; par < 2; ++par) {
+        const int ch = ((lane & 7) ^ lds_swz<BK>(par * RPP + rip)) * 8;
+        va[par] = (unsigned)((rip * ldk + ch) * 2);
+        vw[par] = (unsigned)((wpiece_lane_row<GRP>(rip) * ldk + ch) * 2);
+    }
     const char* abase = (const char*)(A + (size_t)(m0 + wave * RPP * PA) * ldk);
-    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * RPP * PW) * ldk);
+    const char* wbase = (const char*)(Wt + (size_t)n0 * ldk);
     const unsigned lds0 = lds_addr(lds2);
     auto issue = [&](int kt) {
         const unsigned st = lds0 + (kt % RS) * STAGE;
@@ -349,7 +431,10 @@ __global__ __launch_bounds__(256, 1) void gemm128s_kernel(
 #pragma unroll
         for (int j = 0; j < PA; ++j) glds_piece(va[j & 1], abase + (size_t)j * RPP * ldk * 2 + ko, st + (wave * PA + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < PW; ++j) glds_piece(va[j & 1], wbase + (size_t)j * RPP * ldk * 2 + ko, st + BM * BK * 2 + (wave * PW + j) * 1024);
+        for (int j = 0; j < PW; ++j) {
+            const int pi = wave * PW + j;                       // wave-uniform (PW = 4: parity of pi = parity of j)
+            glds_piece(vw[pi & 1], wbase + (size_t)wpiece_row<GRP>(pi) * ldk * 2 + ko, st + BM * BK * 2 + pi * 1024);
+        }
     };
 
     f32x4 acc[MF][NF];
@@ -417,21 +502,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(
     const int m0 = tm * BM, n0 = tn * BN;
 
     // DMA: K-tile = 32 A pieces + 32 W pieces of 1 KiB (8 rows x 128 B); wave w owns A pieces 4w .. 4w+3 and W pieces 4w .. 4w+3
+    constexpr int GRP = EpiGrp<NF, EPI, ODT>::value;       // W rows permuted inside the tile: see EpiGrp
     const int rip = lane >> 3;
-    unsigned vo[2];
+    unsigned vo[2], vwo[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         const int sw = ((par * 8 + rip) >> 1) & 7;
         vo[par] = (unsigned)((rip * K + (((lane & 7) ^ sw) * 8)) * 2);
+        vwo[par] = (unsigned)((wpiece_lane_row<GRP>(rip) * K + (((lane & 7) ^ sw) * 8)) * 2);
     }
     const char* abase = (const char*)(A + (size_t)(m0 + wave * 32) * K);
-    const char* wbase = (const char*)(Wt + (size_t)(n0 + wave * 32) * K);
+    const char* wbase = (const char*)(Wt + (size_t)n0 * K);
     const unsigned lds0 = lds_addr(lds2);
     auto issue4 = [&](int kt, int which) {                  // which = 0: this wave's 4 A pieces, 1: its 4 W pieces
         const unsigned st = lds0 + (kt & 1) * STAGE + (which ? 256 * 128 : 0) + wave * 4096;
-        const char* base = (which ? wbase : abase) + (size_t)kt * BK * 2;
+        if (which) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds_piece(vo[j & 1], base + (size_t)j * 8 * K * 2, st + j * 1024);
+            for (int j = 0; j < 4; ++j)
+                glds_piece(vwo[j & 1], wbase + (size_t)wpiece_row<GRP>(wave * 4 + j) * K * 2 + (size_t)kt * BK * 2, st + j * 1024);
+        } else {
+            const char* base = abase + (size_t)kt * BK * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds_piece(vo[j & 1], base + (size_t)j * 8 * K * 2, st + j * 1024);
+        }
     };
 
     f32x4 acc[MF][NF];
@@ -574,40 +667,8 @@ static hipError_t dispatch_gemm256(hipStream_t st, const bf16* a, const bf16* w,
     return hipErrorInvalidValue;
 }
 
-#ifdef FVHD_DEBUG_KNOBS
-// knob 5 (experiment, debug library only): 256 x 128 tile, 4 waves of 128 x 64, K tiles of 32 in a 72-KB ring -> two workgroups per CU
-static hipError_t dispatch_gemm256_2wg(hipStream_t st, const bf16* a, const bf16* w, const float* bias, const float* ls, const bf16* r, void* out,
-                                       int M, int N, int K, int epi)
-{
-    switch (epi) {
-    case EPI_NONE: return launch_gemm256<EPI_NONE, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_BIAS: return launch_gemm256<EPI_BIAS, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_BIAS_GELU: return launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_BIAS_LS_RESID: return launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_RESID: return launch_gemm256<EPI_RESID, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_SWIGLU: return launch_gemm256<EPI_SWIGLU, FVHD_BF16, 4, 128, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    }
-    return hipErrorInvalidValue;
-}
-#endif
-
-#ifdef FVHD_DEBUG_KNOBS
-// knobs 6 / 7 (experiment, debug library only): the 8-wave 256 x 256 / 256 x 128 tiles with K tiles of 32 and a 4- / 6-stage ring
-template <int BN>
-static hipError_t dispatch_gemm256_bk32(hipStream_t st, const bf16* a, const bf16* w, const float* bias, const float* ls, const bf16* r, void* out,
-                                        int M, int N, int K, int epi)
-{
-    switch (epi) {
-    case EPI_NONE: return launch_gemm256<EPI_NONE, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_BIAS: return launch_gemm256<EPI_BIAS, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_BIAS_GELU: return launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_BIAS_LS_RESID: return launch_gemm256<EPI_BIAS_LS_RESID, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_RESID: return launch_gemm256<EPI_RESID, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    case EPI_SWIGLU: return launch_gemm256<EPI_SWIGLU, FVHD_BF16, 8, BN, 32>(st, a, w, bias, ls, r, out, M, N, K);
-    }
-    return hipErrorInvalidValue;
-}
-#endif
+// (knobs 5 / 6 / 7 of round 4 - K tiles of 32 with two workgroups per CU or 4- / 6-stage rings - measured slower everywhere
+// (profiles/r03_gemm_2wg.log, r04_gemm_bk32_rings.log) and were removed in round 5 together with their dispatchers.)
 
 // 128 x 128 streaming kernel (v1s).  K = the K range of ONE slice, ldk = the row stride, splits = gridDim.y (1 for a plain GEMM)
 template <int EPI, int ODT>
@@ -847,15 +908,12 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     if (g_gemm_v2 && out_dtype == FVHD_BF16 && M % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 128) {
         const long long t128 = (long long)(M / 256) * (N / 128), t256 = N % 256 == 0 ? (long long)(M / 256) * (N / 256) : 0;
 #ifdef FVHD_DEBUG_KNOBS
-        if (g_gemm_v2 == 5) return (int)dispatch_gemm256_2wg(st, a, w, bias, ls, r, out, M, N, K, epi);
         if ((g_gemm_v2 == 8 || g_gemm_v2 == 9) && t256 > 0 && (epi == EPI_NONE || epi == EPI_BIAS_GELU)) {     // ablations of the 256 x 256 kernel
             if (g_gemm_v2 == 8) return (int)(epi == EPI_NONE ? launch_gemm256<EPI_NONE, FVHD_BF16, 8, 256, 64, 1>(st, a, w, bias, ls, r, out, M, N, K)
                                                               : launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8, 256, 64, 1>(st, a, w, bias, ls, r, out, M, N, K));
             return (int)(epi == EPI_NONE ? launch_gemm256<EPI_NONE, FVHD_BF16, 8, 256, 64, 2>(st, a, w, bias, ls, r, out, M, N, K)
                                          : launch_gemm256<EPI_BIAS_GELU, FVHD_BF16, 8, 256, 64, 2>(st, a, w, bias, ls, r, out, M, N, K));
         }
-        if (g_gemm_v2 == 6 && t256 > 0) return (int)dispatch_gemm256_bk32<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
-        if (g_gemm_v2 == 7 || g_gemm_v2 == 6) return (int)dispatch_gemm256_bk32<128>(st, a, w, bias, ls, r, out, M, N, K, epi);
 #endif
         // measured (tools/bench_ops.py gemm, profiles/r03_gemm_tiles.log, B = 32): the 256 x 256 tile wins from N = 2304 on when it has
         // ~2 rounds of tiles - stage-3 qkv 186 -> 165 us, fc1 268 -> 242, stage-4 fc1 224 -> 204, 7B projector 239 / 267 -> 211 / 239 -

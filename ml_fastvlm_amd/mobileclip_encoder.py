@@ -114,15 +114,25 @@ class MobileCLIPVisionTower(nn.Module):
         inv = getattr(args, "mm_vision_batch_invariant", None)
         self.batch_invariant = None if inv is None else bool(inv)
         # precision of the fused ConvFFN's hidden activation (include/fvhd.h "precision of the fused ConvFFN's hidden activation"):
-        # "half" (default; gelu(x)/4 in IEEE half - saturates beyond |fc1 output| = 262 016), "bf16" (every block on the f32-GELU /
-        # bf16-operand form of the same kernel: no range limit, a few % slower) or "auto" (the FIRST batch encoded after a weight load is
-        # also the calibration batch of `audit_ranges()`: one extra eager pass, then only the blocks that need it run the bf16 form).
-        prec = getattr(args, "mm_vision_ffn_precision", None) or "half"
+        # "auto" (DEFAULT since round 5: the first `mm_vision_ffn_audit_batches` non-degenerate batches encoded after a weight load - or an
+        # explicit `calibrate(images)` - run `audit_ranges()` first: one extra eager pass each, then only the blocks that need it run the
+        # bf16 form), "half" (no audit: gelu(x)/4 in IEEE half - saturates beyond |fc1 output| = 262 016; the range guard below still
+        # applies) or "bf16" (every block on the f32-GELU / bf16-operand form of the same kernel: no range limit, a few % slower).
+        prec = getattr(args, "mm_vision_ffn_precision", None) or "auto"
         if prec not in ("half", "bf16", "auto"):
             raise ValueError(f"mm_vision_ffn_precision must be 'half', 'bf16' or 'auto', got {prec!r}")
         self.ffn_precision = prec
-        self._ffn_bf16_steps = set()            # steps an audit moved to the bf16 form (re-applied whenever the weights are re-packed)
-        self._ffn_audited = False               # "auto": has the current weight set seen its calibration batch?
+        self.ffn_audit_batches = max(1, int(getattr(args, "mm_vision_ffn_audit_batches", None) or 2))
+        self._ffn_bf16_steps = set()            # steps an audit / the guard moved to the bf16 form (re-applied whenever the weights are re-packed)
+        self._ffn_audits_left = self.ffn_audit_batches   # "auto": calibration batches the current weight set has still to see
+        # the range guard (include/fvhd.h "range guard"): always on unless "off"; "strict" = poll synchronously after every call and
+        # re-encode the batch when a block crossed its limit (the result of every call is then inside the proven range, at the price of
+        # one host synchronisation per call); "on" (default) = asynchronous: the block is moved before the NEXT call, with a warning
+        guard = getattr(args, "mm_vision_range_guard", None)
+        guard = "on" if guard in (None, True) else "off" if guard is False else guard
+        if guard not in ("on", "off", "strict"):
+            raise ValueError(f"mm_vision_range_guard must be 'on', 'off' or 'strict', got {guard!r}")
+        self.range_guard = guard
         # expected batch size (sizes the library's workspace up front; it grows geometrically when a larger batch arrives)
         self._batch_hint = max(1, int(getattr(args, "mm_vision_max_batch", 1) or 1))
         self._ctx: Optional[_lib.Context] = None
@@ -165,7 +175,12 @@ class MobileCLIPVisionTower(nn.Module):
     def _mark_dirty(self) -> None:
         self._dirty = True
         self._ffn_bf16_steps = set()            # new weights: an earlier range audit says nothing about them
-        self._ffn_audited = False
+        self._ffn_audits_left = self.ffn_audit_batches
+
+    @property
+    def _ffn_audited(self) -> bool:
+        """"auto": has the current weight set seen all of its calibration batches?"""
+        return self._ffn_audits_left <= 0
 
     def _apply(self, fn, *a, **kw):
         # .to() / .half() / .cuda(): parameter storage (and possibly values, through a dtype cast) changes
@@ -189,12 +204,11 @@ class MobileCLIPVisionTower(nn.Module):
             self._dirty = True
             self._projector_src = None
         if self._dirty:
-            for k, v in self.vision_tower.model.state_dict().items():
-                if v.is_floating_point():
-                    self._ctx.set_tensor(k, v)
+            self._ctx.set_tensors(self.vision_tower.model.state_dict())     # one device-to-host transfer for the 629 tensors
             self._ctx.finalize()
             self._dirty = False
             self._apply_ffn_precision(self._ctx)
+        self._ctx.set_range_guard(self.range_guard != "off")
         if self.attention_fp8 is not None:
             self._ctx.set_attention_fp8(self.attention_fp8)
         if self.hip_graph is not None:
@@ -232,7 +246,6 @@ class MobileCLIPVisionTower(nn.Module):
             report.append({"step": i, "kind": kind, "stage": stage, "block": block, "max_abs_fc1": maxes[i],
                            "precision": {-1: "two GEMMs (bf16 hidden tensor in HBM)", 0: "half", 1: "bf16"}[now],
                            "switched": now == _lib.FFN_BF16 and before[i] == _lib.FFN_HALF})
-        self._ffn_audited = True
         if switched:
             import warnings
             hot = [(r["step"], r["max_abs_fc1"]) for r in report if r["switched"]]
@@ -286,9 +299,52 @@ class MobileCLIPVisionTower(nn.Module):
                 self._batch_hint *= 2
             ctx.reserve(self._batch_hint)
 
+    # "auto" audits with a factor 16 (not 4) of headroom below the saturation point: the calibration batches are whatever arrives first
+    AUTO_SWITCH_ABOVE = 16376.0
+
+    def calibrate(self, images: torch.Tensor, switch_above: float = AUTO_SWITCH_ABOVE):
+        """Explicit calibration (round 5): `audit_ranges(images)` on a batch of REAL, preprocessed images, after which "auto" does not audit
+        incoming batches any more.  Call it once per checkpoint before serving (and before capturing the tower into a caller's hipGraph:
+        the audit synchronises).  Returns the audit's report."""
+        report = self.audit_ranges(images, switch_above)
+        self._ffn_audits_left = 0
+        return report
+
+    @staticmethod
+    def _degenerate(images: torch.Tensor) -> bool:
+        """a batch that says nothing about activation ranges: every image constant (zeros / ones warm-up batches, dummy inputs)"""
+        flat = images.reshape(images.shape[0], -1)
+        return bool((flat.amax(dim=1) == flat.amin(dim=1)).all().item())
+
     def _auto_audit(self, images: torch.Tensor) -> None:
-        if self.ffn_precision == "auto" and not self._ffn_audited:
-            self.audit_ranges(images)
+        if self.ffn_precision != "auto" or self._ffn_audits_left <= 0:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return                              # the audit synchronises: a capturing caller calibrates up front (INTEGRATION.md)
+        if self._degenerate(images):
+            return                              # not counted: a zeros warm-up batch must not use up the calibration
+        self.audit_ranges(images, self.AUTO_SWITCH_ABOVE)
+        self._ffn_audits_left -= 1
+
+    def _after_encode(self, ctx, rerun=None):
+        """range guard: report (and remember across re-packs) the blocks the library moved to the bf16-operand form.  "strict": wait for this
+        call's read-back and run the batch again if it crossed a limit."""
+        if self.range_guard == "off":
+            return
+        if self.range_guard == "strict" and torch.cuda.is_current_stream_capturing():
+            return
+        hits = ctx.range_guard_poll(wait=self.range_guard == "strict")
+        if not hits:
+            return
+        import warnings
+        for step, _ in hits:
+            self._ffn_bf16_steps.add(step)
+        warnings.warn("ml_fastvlm_amd range guard: max |A| of the ConvFFN input exceeded the proven half-precision range in step(s) "
+                      f"{[(s, float(a)) for s, a in hits]} (limits: {[ctx.range_guard_limit(s) for s, _ in hits]}); those blocks now run the "
+                      "bf16-operand form of the fused kernel"
+                      + ("" if self.range_guard == "strict" else " - the batch that crossed the limit was computed on the half-precision form"))
+        if self.range_guard == "strict" and rerun is not None:
+            rerun()
 
     def _encode(self, images: torch.Tensor) -> torch.Tensor:
         images = self._check_images(images)
@@ -297,6 +353,7 @@ class MobileCLIPVisionTower(nn.Module):
         self._grow(ctx, images.shape[0])
         out = torch.empty((images.shape[0], ctx.num_tokens, self.hidden_size), device=images.device, dtype=images.dtype)
         ctx.encode(images, out)
+        self._after_encode(ctx, lambda: ctx.encode(images, out))
         return out
 
     def forward_images(self, images):
@@ -361,6 +418,7 @@ class MobileCLIPVisionTower(nn.Module):
             self._grow(ctx, images.shape[0])
             out = torch.empty((images.shape[0], ctx.num_tokens, hid), device=images.device, dtype=images.dtype)
             ctx.encode_images(images, out)
+            self._after_encode(ctx, lambda: ctx.encode_images(images, out))
             return out
 
     # ---- properties (mobileclip_encoder.py:90-116) ---------------------------------------------------
