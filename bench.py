@@ -226,6 +226,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tower-only", action="store_true", help="time the vision tower without the projector")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives, barriers) even at WORLD_SIZE = 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N > 1 path: nccl = RCCL over xGMI (the product path); gloo = host-staged all-gather, for running "
+                         "several ranks on ONE GPU (tests: RCCL refuses two ranks on one device) - never a performance number")
+    ap.add_argument("--same-device", action="store_true", help="with --backend gloo: every rank uses cuda:0 (several ranks on a one-GPU box)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="default run: skip the `c4_1gpu` and `c5` objects (BASELINE configs[3] single-GPU leg, configs[4]) appended to the throughput line")
     ap.add_argument("--ttft-llm", default="kernels", choices=["kernels", "kernels-graph", "hf-graph", "hf-eager"],
                     help="--ttft: prefill on the hand-written kernels (fvhd_llm_prefill; default), the same as one hipGraph, or the stock transformers module (graph / eager)")
     ap.add_argument("--ttft", action="store_true", help="report time-to-first-token of FastVLM prefill instead (tools/ttft.py, BASELINE configs[2]; with --gpus N / "
@@ -246,6 +252,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    if args.same_device:
+        if args.backend != "gloo":
+            raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -253,7 +263,10 @@ def main():
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         trace("init_process_group ...")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         trace("process group up")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -296,12 +309,8 @@ def main():
 
     side = D.gather_side(Hd)                     # 0.5B / 1.5B: gather the projected tokens; 7B (H = 3584 > 3072): gather before the projector
 
-    def _all_gather(t):                          # all_gather_tokens short-cuts world 1; the forced path still issues the collective
-        if world == 1:
-            out = torch.empty_like(t)
-            dist.all_gather_into_tensor(out, t.contiguous())
-            return out
-        return D.all_gather_tokens(t, B * world)
+    def _all_gather(t):                          # (force: the collective is issued at world 1 too)
+        return D.all_gather_tokens(t, B * world, force=True)
 
     @torch.no_grad()
     def step():
@@ -311,6 +320,9 @@ def main():
             return _all_gather(local_step())
         return fv.project(tower, proj, _all_gather(tower(images)))      # fvhd_project: the library's GEMMs, never torch.nn.Linear
 
+    # explicit range calibration of the half-precision fused ConvFFN (the default "auto" would audit the first batches it sees -
+    # two extra eager passes that belong in front of the warm-up, not inside a short timed region); the range guard stays on
+    tower.calibrate(images)
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
@@ -346,7 +358,9 @@ def main():
                                f"{('tokens all-gathered over RCCL ' + side + ' the projector') if multi else 'single GPU'}",
                    "global_batch": B * world, "image_size": R, "tokens_per_image": (R // 64) ** 2, "parallelism": f"dp{world}",
                    "hip_graph": bool(args.graph), "attention_operands": "e4m3" if args.attn_fp8 else "bf16",
-                   **({"collective": f"all_gather_into_tensor over nccl (RCCL), world {world}", "gather_side": side} if multi else {})},
+                   "ffn_precision": "auto (calibrated on the benchmark batch), range guard on",
+                   **({"collective": f"all_gather_into_tensor over {'nccl (RCCL)' if args.backend == 'nccl' else 'gloo (host-staged; test only)'}, world {world}",
+                       "gather_side": side} if multi else {})},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -422,6 +436,47 @@ def main():
         except Exception as e:                                # the latency leg must not cost the throughput line
             result["ttft"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         trace("ttft leg done")
+
+    if rank == 0 and world == 1 and not args.no_extra_configs and not args.no_ttft and R == 1024 and not args.tower_only and B == 32 and Hd == 896:
+        # the remaining BASELINE.json configs on the driver's clock, a few seconds each:
+        # c4_1gpu - the single-GPU leg of configs[3]: 8 images, FastVLM-7B widths (Qwen2-7B, 28 layers, 7.6 B random bf16 parameters), TTFT
+        #           with the gather side of the 7B model's projector; the 8-GPU all-gather leg is `bench.py --ttft --hidden 3584 --gpus 8`
+        # c5      - configs[4]: 1536 x 1536, batch 16, e4m3 MFMA operands in the attention cores (`--res 1536 --batch 16 --attn-fp8`)
+        del out
+        try:
+            import ttft
+            t = ttft.measure(8, R, 3584, steps=5, warmup=2, dev=dev, llm_mode="kernels")
+            result["c4_1gpu"] = {"metric": "TTFT FastVLM-7B prefill, batch=8 @1024x1024 bf16, one GPU's share of configs[3]", "value": t["ttft_ms_median"],
+                                 "unit": "ms", "higher_is_better": False, "workload": "BASELINE.json configs[3], single-GPU leg (no collective)", **t}
+        except Exception as e:
+            result["c4_1gpu"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+        trace("c4_1gpu leg done")
+        try:
+            t5 = fv.MobileCLIPVisionTower("mobileclip_l_1536", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_attention_fp8=True, mm_vision_max_batch=16))
+            t5.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234), strict=True)
+            t5 = t5.to(dev, torch.bfloat16)
+            x5 = torch.rand((16, 3, 1536, 1536), generator=torch.Generator(device="cpu").manual_seed(2000)).to(dev, torch.bfloat16)
+            with torch.no_grad():
+                t5.calibrate(x5)
+                for _ in range(2):
+                    o5 = fv.encode_images(t5, proj, x5)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    o5 = fv.encode_images(t5, proj, x5)
+                torch.cuda.synchronize()
+                d5 = time.perf_counter() - t0
+            assert torch.isfinite(o5.float()).all()
+            result["c5"] = {"metric": "images/sec FastViTHD encode_images @1536x1536, e4m3 attention operands", "value": round(16 * 5 / d5, 2), "unit": "images/sec",
+                            "higher_is_better": True, "ms_per_step": round(1e3 * d5 / 5, 3), "steps": 5, "warmup": 2, "batch": 16,
+                            "workload": "BASELINE.json configs[4]: FastViTHD at 1536x1536, batch=16, fp8 (e4m3) MFMA attention path, 1 GPU",
+                            "tokens_per_image": 576, "attention_operands": "e4m3", "dtype": "bf16 (attention operands e4m3)"}
+            del t5, x5, o5
+        except Exception as e:
+            result["c5"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+        trace("c5 leg done")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(R, Hd)

@@ -308,7 +308,9 @@ void fvhd_llm_destroy(fvhd_llm* ctx);
 int fvhd_llm_set_tensor(fvhd_llm* ctx, const char* key, const void* host_data, int dtype, const int64_t* shape, int ndim);
 /* The same tensor from DEVICE memory on the context's device (a model that already lives on the GPU): matrices must be FVHD_BF16 and
  * vectors FVHD_F32, row-major contiguous; packed by one device-to-device (2-D) copy on `stream` - no host round trip.  The caller keeps
- * dev_data alive until `stream` has run the copy. */
+ * dev_data alive until `stream` has run the copy.  STREAM CONTRACT (round 5): the copies are asynchronous; fvhd_llm_finalize waits (on the
+ * host) for all of them, so after it returns a prefill may run on ANY stream; a tensor re-set after fvhd_llm_finalize is ordered before
+ * the next fvhd_llm_prefill by an event (stream wait; a host wait when that prefill's stream is being captured). */
 int fvhd_llm_set_tensor_device(fvhd_llm* ctx, const char* key, const void* dev_data, int dtype, const int64_t* shape, int ndim,
                                fvhd_stream_t stream);
 int fvhd_llm_finalize(fvhd_llm* ctx);                          /* fails if a tensor is missing */

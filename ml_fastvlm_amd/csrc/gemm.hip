@@ -707,14 +707,31 @@ static hipError_t dispatch_gemm128s(hipStream_t st, const bf16* a, const bf16* w
 // down_proj 63.4 -> 52.6, the tower at B = 1: stage-2 fc2 24.6 -> 21.3, stage-4 qkv / fc1 22.0 / 24.9 -> 19.0 / 21.5 - behind it from ~300 on
 // (v1 then has 2-4 workgroups per CU covering each other's latency: stage-2 fc1 at B = 1, 384 tiles, 16.1 -> 21.0), and behind v1 for the
 // slices of a split-K launch with 250-500 workgroups (llm down / 4: 39.7 -> 43.0)
-#ifndef FVHD_GEMM128S_MAX_TILES
-#define FVHD_GEMM128S_MAX_TILES 256        // workgroups of one launch up to which v1s is taken (0 = never): one round of one workgroup per CU
+// Compute units of the current device (round 5, advisor: the dispatch rules below were written as multiples of MI355X's 256 CUs; a
+// partitioned mode - CPX / DPX - or another part changes the count, and with it where "one round of tiles" ends).  Kernel choice only:
+// every kernel gives identical bits.
+static int cu_count()
+{
+    static int cached[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& n = cached[dev & 63];
+    if (n <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
+#ifndef FVHD_GEMM128S_ROUNDS
+#define FVHD_GEMM128S_ROUNDS 1             // v1s is taken up to this many workgroups per CU in one launch (0 = never): one round of one workgroup per CU
 #endif
 static bool take_gemm128s(int M, int N, int K, long workgroups)
 {
     if (M % 128 || N % 128 || K % 64 || K < 128) return false;
     if (g_gemm_v2 == 10) return true;
-    return g_gemm_v2 == 1 && workgroups <= FVHD_GEMM128S_MAX_TILES;
+    return g_gemm_v2 == 1 && workgroups <= (long)FVHD_GEMM128S_ROUNDS * cu_count();
 }
 
 static hipError_t launch_splitk_partials(hipStream_t st, const void* A, const void* Wt, float* partial, int M, int N, int K, int splits)
@@ -833,8 +850,10 @@ extern "C" int fvhd_gemm_splitk_plan(int M, int N, int K)
 {
     if (M <= 0 || N % 128 || K % 64) return 1;
     const long tiles = (long)((M + 127) / 128) * (N / 128);
+    // at most two workgroups per CU - and never more (tile, slice) pairs than the caller's partial buffer holds (512: fvhd_api.hip kSplitKPartialBytes)
+    const long cap = 2l * cu_count() < 512 ? 2l * cu_count() : 512;
     for (int sp = 16; sp > 1; sp >>= 1)
-        if (tiles * sp <= 512 && (K / 64) % sp == 0 && K / sp >= 384 && K >= 2048) return sp;     // (K < 2048: the reduce costs more than the K steps saved - v1s unsplit)
+        if (tiles * sp <= cap && (K / 64) % sp == 0 && K / sp >= 384 && K >= 2048) return sp;     // (K < 2048: the reduce costs more than the K steps saved - v1s unsplit)
     return 1;
 }
 
@@ -919,16 +938,17 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
         // ~2 rounds of tiles - stage-3 qkv 186 -> 165 us, fc1 268 -> 242, stage-4 fc1 224 -> 204, 7B projector 239 / 267 -> 211 / 239 -
         // ties or loses below (N = 768: 64 -> 74 us) and with 1.3 rounds (prefill gate|up, 342 tiles: 59 -> 65).  All three kernels
         // produce identical bits (same K order per output element).
-        const bool use256 = g_gemm_v2 == 3 ? t256 > 0 : (g_gemm_v2 == 1 && N >= 2304 && t256 >= 448);
+        const long long ncu = cu_count();              // 256 on MI355X: the measured thresholds below are 1.75 / 2 / 4 / 0.5 rounds of it
+        const bool use256 = g_gemm_v2 == 3 ? t256 > 0 : (g_gemm_v2 == 1 && N >= 2304 && t256 * 4 >= ncu * 7);
         // 256 x 128 (one workgroup per CU): from two rounds of tiles on, unless the last round is mostly empty (B = 8 stage-3 qkv, 576 tiles = 2.25
         // rounds: v1 46.9 vs 52.1 us; the prefill's gate|up, 684 tiles = 2.67 rounds, stays: 58.7 vs 62.3) - and already from half a round when K is
         // long (K >= 3072: B = 8 stage-3 fc2 64.7 -> 55.5 us, the 0.5B projector's fc 66.5 -> 54.7; profiles/r04_gemm_small_batch.log, r03_gemm_tiles.log)
-        const long long rounds128 = (t128 + 255) / 256;
-        const bool full_enough = t128 >= 1024 || t128 * 5 >= rounds128 * 256 * 4;            // >= 80 % of the slots of its rounds
-        const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && ((t128 >= 512 && full_enough) || (t128 >= 128 && K >= 3072)));
+        const long long rounds128 = (t128 + ncu - 1) / ncu;
+        const bool full_enough = t128 >= 4 * ncu || t128 * 5 >= rounds128 * ncu * 4;            // >= 80 % of the slots of its rounds
+        const bool use128 = g_gemm_v2 == 2 || (g_gemm_v2 == 1 && ((t128 >= 2 * ncu && full_enough) || (t128 * 2 >= ncu && K >= 3072)));
         // ping-pong kernel: same tile, +0-6 % over the plain 256 x 256 kernel, the more the longer K (profiles/r03_gemm_tiles.log: stage-4 fc2
         // K = 6144 185 -> 177 us, 7B projector K = 3584 243 -> 228 us = 0.92 PF/s; K = 768 shapes tie) - taken for K >= 3072
-        if ((g_gemm_v2 == 4 && t256 > 0) || (g_gemm_v2 == 1 && K >= 3072 && t256 >= 128))
+        if ((g_gemm_v2 == 4 && t256 > 0) || (g_gemm_v2 == 1 && K >= 3072 && t256 * 2 >= ncu))
             return (int)dispatch_gemm_pp(st, a, w, bias, ls, r, out, M, N, K, epi);
         if (use256) return (int)dispatch_gemm256<256>(st, a, w, bias, ls, r, out, M, N, K, epi);
         if (use128) return (int)dispatch_gemm256<128>(st, a, w, bias, ls, r, out, M, N, K, epi);

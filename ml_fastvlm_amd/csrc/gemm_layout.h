@@ -6,8 +6,14 @@
 #define FVHD_EPI_SWIGLU_ID 5
 #define FVHD_ODT_BF16_ID 2
 
+// -DFVHD_GEMM_GRP1 (experiments: FVHD_VARIANT_TAG=g1 FVHD_EXTRA_DEFS=-DFVHD_GEMM_GRP1 python -m ml_fastvlm_amd.build -> libfvhd_g1.so): the
+// round-4 layout everywhere (identity permutation, 8-B / 4-B stores) for same-box A/B runs and a bit-for-bit comparison of the outputs
 template <int NF, int EPI, int ODT> struct EpiGrp {
+#ifdef FVHD_GEMM_GRP1
+    static constexpr int value = 1;
+#else
     static constexpr int value = (ODT != FVHD_ODT_BF16_ID || (NF % 2)) ? 1 : (EPI == FVHD_EPI_SWIGLU_ID && NF % 4 == 0) ? 4 : 2;
+#endif
 };
 template <int GRP> constexpr int wrow_of_lds_row(int p)
 {

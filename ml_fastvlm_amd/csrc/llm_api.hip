@@ -100,6 +100,11 @@ struct fvhd_llm {
     bool ws_captured = false;
     std::vector<char*> retired;
     int generation = 0;
+    // fvhd_llm_set_tensor_device enqueues its copies on the CALLER's stream: `load_ev` is recorded behind the latest one so that
+    // fvhd_llm_finalize (host wait) and fvhd_llm_prefill (stream wait, whatever stream it runs on) are ordered after the packing
+    hipEvent_t load_ev = nullptr;
+    hipStream_t load_stream = nullptr;
+    bool load_pending = false;
 };
 
 namespace {
@@ -260,6 +265,7 @@ void fvhd_llm_destroy(fvhd_llm* c)
     if (c->wdev) (void)hipFree(c->wdev);
     if (c->ws) (void)hipFree(c->ws);
     for (char* p : c->retired) (void)hipFree(p);
+    if (c->load_ev) (void)hipEventDestroy(c->load_ev);
     delete c;
 }
 
@@ -346,7 +352,23 @@ int fvhd_llm_set_tensor_device(fvhd_llm* c, const char* key, const void* dev_dat
     hipError_t e = vec ? hipMemcpyAsync(c->wdev + off, dev_data, rows * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream)
                        : hipMemcpy2DAsync(c->wdev + off, pitch * 2, dev_data, cols * 2, cols * 2, rows, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e != hipSuccess) return lhip("hipMemcpyAsync(llm weights, device to device)", e);
+    // order later work after this copy (advisor, round 4: a prefill on ANOTHER stream could read half-packed weights)
+    if (!c->load_ev && (e = hipEventCreateWithFlags(&c->load_ev, hipEventDisableTiming)) != hipSuccess) return lhip("hipEventCreate", e);
+    if (c->load_pending && c->load_stream != (hipStream_t)stream) (void)hipEventSynchronize(c->load_ev);   // copies on a second stream: the event follows one stream at a time
+    if ((e = hipEventRecord(c->load_ev, (hipStream_t)stream)) != hipSuccess) return lhip("hipEventRecord", e);
+    c->load_stream = (hipStream_t)stream;
+    c->load_pending = true;
     c->got[idx] = 1;
+    return 0;
+}
+
+// every copy fvhd_llm_set_tensor_device has enqueued so far has completed (host wait); the caller holds a DevGuard
+static int wait_for_loads(fvhd_llm* c)
+{
+    if (!c->load_pending) return 0;
+    const hipError_t e = hipEventSynchronize(c->load_ev);
+    if (e != hipSuccess) return lhip("hipEventSynchronize(llm weights)", e);
+    c->load_pending = false;
     return 0;
 }
 
@@ -368,7 +390,9 @@ int fvhd_llm_finalize(fvhd_llm* c)
             return lfail("fvhd_llm_finalize: missing tensor (layer " + std::to_string(l) + ", slot " + std::to_string(w) +
                          "; slots: ln1 q.w q.b k.w k.b v.w v.b o.w ln2 gate up down | norm lm_head)");
         }
-    return 0;
+    DevGuard g(c->device);
+    if (g.err != hipSuccess) return lhip("hipSetDevice", g.err);
+    return wait_for_loads(c);               // the device-to-device packing is complete when this returns (include/fvhd.h "stream contract")
 }
 
 int fvhd_llm_reserve(fvhd_llm* c, int batch, int seq_len)
@@ -395,7 +419,18 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
     if (e) return e;
     {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) c->ws_captured = true;
+        const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        if (capturing) c->ws_captured = true;
+        // tensors re-set after fvhd_llm_finalize: this prefill runs behind their copies (a captured stream cannot wait on an outside
+        // event - there the host waits once)
+        if (c->load_pending) {
+            if (hipEventQuery(c->load_ev) == hipSuccess) c->load_pending = false;
+            else if (capturing || st == c->load_stream) { if (capturing && (e = wait_for_loads(c))) return e; }
+            else {
+                const hipError_t he = hipStreamWaitEvent(st, c->load_ev, 0);
+                if (he != hipSuccess) return lhip("hipStreamWaitEvent(llm weights)", he);
+            }
+        }
     }
     const int B = batch, T = seq_len, M = B * T, Mp = (M + 255) / 256 * 256;
     const int H = c->H, I = c->I, nh = c->nh, nkv = c->nkv, hd = c->hd;
@@ -411,10 +446,13 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
     // the largest split that still fits ONE round of the streaming 128 x 128 kernel (<= 256 workgroups: gemm.hip v1s) - else, as in round 3, the
     // largest within two v1 workgroups per CU.  0.5 B at B = 8 (126 tiles): down_proj in TWO slices of 38 K steps on v1s instead of four of
     // 19 on v1, 33 -> 16 MB of partials: prefill 3.92 -> 3.77 ms (profiles/r04_ttft_down_split.log)
+    int ncu_ = 0;
+    if (hipDeviceGetAttribute(&ncu_, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu_ <= 0) ncu_ = 256;
+    const long ncu = ncu_;
     auto pick_splits = [&](int N, int K, int max_sp) {
         const long tiles = (long)(Mp / 128) * (N / 128);
         if (N % 128 == 0)
-            for (long cap = 256; cap <= 512; cap += 256)
+            for (long cap = ncu; cap <= 2 * ncu; cap += ncu)        // one round, then two rounds, of one workgroup per CU (256 / 512 on MI355X)
                 for (int sp = kMaxSplits; sp > 1; sp >>= 1)
                     if (sp <= max_sp && tiles * sp <= cap && K % (64 * sp) == 0) return sp;
         return 1;

@@ -35,12 +35,26 @@ def shard_images(images: torch.Tensor, rank: Optional[int] = None, world: Option
     return images[lo:hi]
 
 
-def all_gather_tokens(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
+def all_gather_into(out: torch.Tensor, local: torch.Tensor, group=None) -> torch.Tensor:
+    """`dist.all_gather_into_tensor(out, local)` for whatever backend the group runs on.  RCCL ("nccl") and gloo-on-CPU take the tensors
+    as they are; gloo has no all-gather for DEVICE tensors, so there the message is staged through the host (round 5: the only way to run
+    the real tower under world size > 1 on a ONE-GPU box - RCCL refuses two ranks on one device - and a debugging aid elsewhere; never the
+    production path, where the backend is nccl and the tokens go GPU to GPU over xGMI)."""
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        host_out = torch.empty(out.shape, dtype=out.dtype, device="cpu")
+        dist.all_gather_into_tensor(host_out, local.contiguous().cpu(), group=group)
+        out.copy_(host_out)
+        return out
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
+
+
+def all_gather_tokens(local: torch.Tensor, global_batch: int, group=None, force: bool = False) -> torch.Tensor:
     """local [b_r, T, H] on each rank (b_r from `shard_bounds`) -> [global_batch, T, H] on every rank,
     in image order.  Equal shards take the single-message path; ragged shards are padded to the
-    largest shard for the collective and trimmed afterwards."""
+    largest shard for the collective and trimmed afterwards.  force: issue the collective at world size 1 too (tests / `--force-dist`)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return local
     sizes = [shard_bounds(global_batch, r, world) for r in range(world)]
     counts = [hi - lo for lo, hi in sizes]
@@ -48,12 +62,11 @@ def all_gather_tokens(local: torch.Tensor, global_batch: int, group=None) -> tor
     tail = tuple(local.shape[1:])
     if min(counts) == bmax:
         out = torch.empty((global_batch,) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
+        return all_gather_into(out, local, group=group)
     padded = torch.zeros((bmax,) + tail, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     buf = torch.empty((world * bmax,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, padded, group=group)
+    all_gather_into(buf, padded, group=group)
     return torch.cat([buf[r * bmax: r * bmax + counts[r]] for r in range(world)], 0)
 
 

@@ -61,3 +61,75 @@ def test_bench_distributed_path_world2_nccl():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
     d7 = _torchrun_bench(2, ("--hidden", "3584"))             # FastVLM-7B width: gather BEFORE the projector
     assert d7["config"]["gather_side"] == "before"
+
+
+# ---- world size 2 with the REAL tower, on ONE GPU ---------------------------------------------------------------------
+# RCCL refuses two ranks on one device, so the two processes share cuda:0 under the gloo backend (the visual tokens are staged through the
+# host for the collective: distributed.all_gather_into).  What this proves is everything EXCEPT the wire: shard order, ragged shards, the
+# gather side, the library projector after the gather - bit for bit against a single-process encode of the whole batch (batch-invariant
+# kernel selection: an image gives the same bits in any batch; reference semantics: images are independent, mobileclip_encoder.py:78-83,
+# llava_arch.py:154-160).
+def _real_tower_worker(rank, world, port, global_batch, q):
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    import ml_fastvlm_amd as fv
+    from ml_fastvlm_amd import distributed as D
+    from ml_fastvlm_amd import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        tower = fv.MobileCLIPVisionTower("mobileclip_l_256", SimpleNamespace(unfreeze_mm_vision_tower=False, mm_vision_batch_invariant=True))
+        tower.vision_tower.model.load_state_dict(synth.synthetic_state_dict(1234, "mild"), strict=True)
+        tower = tower.to(dev, torch.bfloat16)
+        images = synth.synthetic_images(global_batch, 256, seed=23).to(dev, torch.bfloat16)       # the same batch on both ranks
+        ok, notes = True, []
+        with torch.no_grad():
+            for hidden, side in ((896, "after"), (3584, "before")):
+                proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=hidden))
+                proj.load_state_dict(synth.synthetic_projector_state_dict(hidden, 1234), strict=True)
+                proj = proj.to(dev, torch.bfloat16)
+                want = fv.encode_images(tower, proj, images)                                    # single-process result for the whole batch
+                local = D.shard_images(images)
+                assert D.gather_side(hidden) == side
+                got = D.encode_images_tower_sharded(tower, proj, local, global_batch)
+                same = got.shape == want.shape and torch.equal(got, want)
+                notes.append(f"H={hidden} side={side} shard={tuple(local.shape)} equal={same}")
+                ok = ok and same
+                # ... and the other side explicitly: the two orders of gather and projector agree bit for bit as well
+                other = D.encode_images_tower_sharded(tower, proj, local, global_batch, side="before" if side == "after" else "after")
+                ok = ok and torch.equal(other, want)
+        torch.cuda.synchronize()
+        q.put((rank, bool(ok), notes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_batch", [4, 5])      # equal shards, and a ragged split (3 + 2: padded for the collective, trimmed after)
+def test_world2_real_tower_on_one_gpu_equals_single_process(global_batch):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_tower_worker, args=(r, 2, port, global_batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    print(res)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
+
+
+def test_ttft_harness_world2_on_one_gpu_gloo():
+    """`bench.py --ttft --gpus 2` (BASELINE.json configs[3] harness) with two ranks on cuda:0 under gloo: encode sharded over the ranks ->
+    all-gather at the projector boundary (before it at the 7B width) -> every rank prefills its own sequences -> max over ranks."""
+    for hidden, side in ((3584, "before"), (896, "after")):
+        d = _torchrun_bench(2, ("--ttft", "--hidden", str(hidden), "--llm-layers", "2", "--batch", "2", "--backend", "gloo", "--same-device"))
+        c = d["config"]
+        assert d["n_gpus"] == 2 and d["unit"] == "ms" and d["value"] > 0
+        assert c["world"] == 2 and c["global_batch"] == 4 and c["gather_side"] == side and "gloo" in c["collective"]
+    d = _torchrun_bench(2, ("--backend", "gloo", "--same-device"))               # the throughput line's N > 1 path, two ranks on one device
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and "gloo" in d["config"]["collective"] and d["value"] > 0

@@ -404,6 +404,63 @@ def test_dwconv_no_bias():
     _close(y.permute(0, 3, 1, 2), F.conv2d(x.float(), w, None, padding=3, groups=C), what="dwconv no bias")
 
 
+@pytest.mark.parametrize("Cin,H,W,B,mfma", [
+    (192, 40, 128, 2, 1),        # matrix-core kernel: two full strips, 8-row chunks (the rows above a chunk must not count)
+    (128, 70, 96, 2, 1),         # ... ragged second strip: the maximum is taken over the strip's 64 columns (zero-extended image)
+    (96, 37, 70, 3, 1),          # ... 96-channel workgroups
+    (64, 3, 64, 1, 1),           # ... fewer rows than taps: every output row comes from the tail loop
+    (384, 64, 64, 24, 1),        # ... 16-row chunks (the shape class of stage 2)
+    (192, 11, 9, 2, 0),          # VALU kernel: one ragged tile
+    (96, 40, 37, 2, 0),          # ... 96 channels, several tiles, LDS-DMA variant
+    (768, 12, 12, 1, 0),         # ... register-staged variant (C = 768)
+])
+def test_dw7_amax_for_the_range_guard(Cin, H, W, B, mfma):
+    """fvhd_op_dw7_amax (round 5): the ConvFFN's depthwise 7x7 with max |output| reduced on the fly - the input of the range guard of the
+    half-precision fused ConvFFN.  The convolution's output is the BITS of the plain entry point; the maximum is that of the fp32
+    accumulators (before the rounding to bf16) over the stored rows and, for the matrix-core kernel, over the 64-px strips (a superset
+    of the image when W % 64 != 0).  Tolerance on the maximum: fp32 accumulation order, 1e-5 relative."""
+    lib = _lib.load()
+    x = _bf(_rand(B, Cin, H, W, seed=11))
+    w = _rand(Cin, 1, 7, 7, seed=12, scale=1.0 / 7)
+    b = _rand(Cin, seed=13, scale=0.2)
+    # one hot pixel somewhere below the first chunk boundary and near the right edge: the maximum must come from IT
+    x[B - 1, 5 % Cin, H - 1, W - 2] = 256.0
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y, y0 = (torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    wd, bd = _pack_dw(w).to(DEV), b.to(DEV)
+    bits = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.fvhd_op_dw7_amax(_stream(), _p(xn), _p(y), _p(wd), _p(bd), B, H, W, Cin, mfma, _p(bits)), "dw7 amax")
+    if mfma:
+        _lib.check(lib.fvhd_op_dw7_mfma(_stream(), _p(xn), _p(y0), _p(wd), _p(bd), B, H, W, Cin), "dw7 mfma")
+    else:
+        _lib.check(lib.fvhd_op_dwconv(_stream(), _p(xn), _p(y0), _p(wd), _p(bd), B, H, W, Cin, 7, 1, 1, 0), "dwconv")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0), "the reduction must not change the convolution"
+    got = bits.view(torch.float32).item()
+    wq = _bf(w).float() if mfma else w                       # the matrix-core kernel rounds its taps to bf16
+    Wext = -(-W // 64) * 64 if mfma else W
+    xe = F.pad(x.float(), (0, Wext - W))                     # zeros right of the image: what the masked columns of a strip see
+    want = F.conv2d(xe, wq, b, padding=3, groups=Cin)[..., :Wext].abs().max().item()
+    inside = F.conv2d(x.float(), wq, b, padding=3, groups=Cin).abs().max().item()
+    assert want >= 20.0, "the hot pixel dominates"
+    assert abs(got - want) <= 1e-5 * want, (got, want)
+    assert got >= inside * (1 - 1e-5) and got >= y.float().abs().max().item() * (1 - 2.0 ** -8)
+    # a second launch into the same word only ever raises it (atomicMax on the bit pattern)
+    _lib.check(lib.fvhd_op_dw7_amax(_stream(), _p(torch.zeros_like(xn)), _p(y), _p(wd), None, B, H, W, Cin, mfma, _p(bits)), "dw7 amax")
+    torch.cuda.synchronize()
+    assert bits.view(torch.float32).item() == got
+
+
+def test_dw7_amax_entry_point_checks_its_kernel_choice():
+    lib = _lib.load()
+    x = torch.zeros(24, 64, 64, 192, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(49, 192, device=DEV)
+    bits = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert lib.fvhd_op_dw7_amax(_stream(), _p(x), _p(x), _p(w), None, 24, 64, 64, 192, 0, _p(bits)) != 0    # dispatches to the matrix cores
+    assert lib.fvhd_op_dw7_amax(_stream(), _p(x), _p(x), _p(w), None, 1, 8, 8, 64, 1, _p(bits)) != 0        # W < 16: not that kernel's shape
+    assert lib.fvhd_op_dw7_amax(_stream(), _p(x), _p(x), _p(w), None, 1, 8, 8, 64, 0, None) != 0
+
+
 # ------------------------------------------------------------------------------------------- layernorm
 @pytest.mark.parametrize("M,C", [(37, 768), (5, 1536), (9, 96), (3, 2048)])
 def test_layernorm(M, C):

@@ -193,3 +193,57 @@ def test_reference_generate_with_our_tower_underneath():
     for b in range(3):
         if margin[b] > 2 * err[b]:
             assert seq[b, 0] == seq_ref[b, 0], f"sample {b}: greedy first token differs although the reference's margin exceeds the error"
+
+
+def test_drop_in_defaults_are_range_safe_on_a_saturating_checkpoint():
+    """a checkpoint whose ConvFFN block leaves the half-precision range, the reference's model class, ONLY
+    `install_into_llava()` + `model.encode_images(images)` - no precision option, no audit call - against the reference's own modules in
+    fp32 on PyTorch-ROCm.  STATED TOLERANCE: the tower tolerance of SURVEY.md 8c on the projected tokens, rel-L2 <= 1.5e-2, cosine >= 0.9998
+    (the scaled block is a harsher network than the mild profile: its first call must ALREADY be inside it)."""
+    ref_import.install_timm_stub()
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    import llava.model.llava_arch as arch
+    import llava.model.multimodal_encoder.builder as enc_builder
+    from llava.model.language_model.llava_qwen import LlavaQwen2ForCausalLM
+    saved = (enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images)
+    hidden = 128
+    # stage 1, block 3: fc1.weight x 2^22, layer scale x 2^-22 (tests/test_gpu_ffn_precision.py: hidden pre-activations ~1.6e6 on these images)
+    tower_sd = synth.synthetic_state_dict(1234, "mild")
+    tower_sd["network.2.3.convffn.fc1.weight"] *= 2.0 ** 22
+    tower_sd["network.2.3.layer_scale"] *= 2.0 ** -22
+    proj_sd = synth.synthetic_projector_state_dict(hidden, 1234)
+    images = synth.synthetic_images(2, 256, seed=5).to(DEV)
+    try:
+        torch.manual_seed(0)
+        ref_model = LlavaQwen2ForCausalLM(_llava_cfg(hidden))                       # un-patched: the reference's own tower and projector
+        ref_model.get_vision_tower().vision_tower.model.load_state_dict(tower_sd, strict=True)
+        ref_model.get_model().mm_projector.load_state_dict(proj_sd, strict=True)
+        state = {k: v.clone() for k, v in ref_model.state_dict().items()}
+        ref_model = ref_model.to(DEV).eval()
+        with torch.inference_mode(), torch.backends.cudnn.flags(enabled=False):
+            want = ref_model.encode_images(images).float().cpu()                     # llava_arch.py:141-144, fp32
+        del ref_model
+
+        fv.install_into_llava()                                                      # the whole patch; nothing else is configured
+        cfg = _llava_cfg(hidden)
+        cfg.mm_vision_batch_invariant = True     # (a 256-px, 2-image batch is below the fused kernels' fill rule: make them run - not a safety option)
+        model = LlavaQwen2ForCausalLM(cfg)
+        assert isinstance(model.get_vision_tower(), fv.MobileCLIPVisionTower)
+        missing, unexpected = model.load_state_dict(state, strict=True)
+        assert not missing and not unexpected
+        model = model.to(DEV).eval()
+        import warnings
+        with torch.inference_mode(), warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = model.encode_images(images).float().cpu()                          # FIRST call
+        rel, cos, mx = _metrics(got, want)
+        print(f"saturating checkpoint through install_into_llava() defaults: first encode_images rel-L2 {rel:.3e} cos {cos:.6f}")
+        assert rel <= 1.5e-2 and cos >= 0.9998, (rel, cos, mx)
+        tower = model.get_vision_tower()
+        assert tower.ffn_precision == "auto" and tower.range_guard == "on"
+        assert any("ConvFFN block" in str(w.message) for w in caught), "the switch is reported"
+        with torch.inference_mode():
+            assert torch.equal(model.encode_images(images).float().cpu(), got)
+    finally:
+        enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images = saved

@@ -101,6 +101,31 @@ final)      # evidence of the final binary: bench line, small batches, PMC passe
     timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_ttft_trace -o ttft -- python bench.py --ttft --steps 4 --warmup 1 > gpurun_out/${TAG}_ttft_trace.log 2>&1
     python tools/rocpd_summary.py gpurun_out/${TAG}_ttft_trace/ttft_results.db > ${O}_ttft_kernel_trace.md 2>&1; rm -rf gpurun_out/${TAG}_ttft_trace; head -30 ${O}_ttft_kernel_trace.md | cut -c1-160
     ;;
+r5a)        # round 5, first call: whole GPU suite (all failures, not -x), the driver's line, GEMM layout A/B (bits + time), WRITE_SIZE of the GEMM classes
+    timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --durations=8 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -30 ${O}_pytest.log | cut -c1-300
+    timeout 900 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cut -c1-400 ${O}_bench.json; tail -3 ${O}_bench.err
+    python tools/gemm_bits.py > ${O}_gemm_bits_base.json 2>${O}_gemm_bits.err; FVHD_LIB=ml_fastvlm_amd/libfvhd_g1.so python tools/gemm_bits.py > ${O}_gemm_bits_g1.json 2>>${O}_gemm_bits.err
+    python tools/gemm_bits.py --diff ${O}_gemm_bits_base.json ${O}_gemm_bits_g1.json | tee ${O}_gemm_bits_diff.log
+    for lib in base g1; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_gemm_${lib}.json 2>/dev/null; python - <<PY | tee -a ${O}_gemm_ab.log
+import json
+d=json.load(open("${O}_bench_gemm_${lib}.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("gemm") or k in ("projector", "dw7", "dw3", "ffn_fused")})
+PY
+    done
+    CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-ttft"
+    for lib in base; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        for pass in trace write; do
+            extra=""; [ "$pass" = write ] && extra="--pmc WRITE_SIZE"
+            FVHD_LIB=$L timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_${lib}_${pass} -o ${pass} $extra -- $CMD > gpurun_out/${TAG}_${lib}_${pass}.log 2>&1
+        done
+        python tools/pmc_summary.py ${TAG}_${lib} gpurun_out/${TAG}_${lib}_trace gpurun_out/${TAG}_${lib}_write > ${O}_${lib}_write_summary.md 2>${O}_${lib}_write_summary.err
+        cp profiles/${TAG}_${lib}_pmc_summary.json gpurun_out/ 2>/dev/null; rm -f profiles/${TAG}_${lib}_pmc_summary.json
+        rm -rf gpurun_out/${TAG}_${lib}_trace gpurun_out/${TAG}_${lib}_write
+        grep -i "gemm\|class" ${O}_${lib}_write_summary.md | cut -c1-220
+    done
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;

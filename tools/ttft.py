@@ -105,6 +105,7 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
         side = D.gather_side(hidden)
     g = torch.Generator().manual_seed(11 + rank)
     images = torch.rand((batch, 3, res, res), generator=g).to(dev, torch.bfloat16)
+    tower.calibrate(images)                  # explicit range calibration ("auto" would otherwise audit inside the first timed steps)
     ids = torch.randint(0, 151000, (batch, PROMPT_BEFORE + 1 + PROMPT_AFTER), generator=g)
     ids[:, PROMPT_BEFORE] = S.IMAGE_TOKEN_INDEX
     ids = ids.to(dev)
@@ -151,12 +152,8 @@ def measure(batch: int, res: int, hidden: int, steps: int, warmup: int, dev, gra
     else:
         note = "stock transformers module, eager"
 
-    def gather(t):                           # all_gather_tokens short-cuts world 1; the forced path still issues the collective
-        if world == 1:
-            out_ = torch.empty_like(t)
-            dist.all_gather_into_tensor(out_, t.contiguous())
-            return out_
-        return D.all_gather_tokens(t, batch * world)
+    def gather(t):                           # (force: the collective is issued at world 1 too - `--force-dist`)
+        return D.all_gather_tokens(t, batch * world, force=True)
 
     def once():
         ev[0].record()
