@@ -313,7 +313,7 @@ extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, cons
 
 // batch_invariant != 0: the kernel choice may depend on the SHAPE of one image only, never on B (bit-identical rows whatever the
 // batch they travel in); 0: the fastest kernel for this B (the VALU dw7x7 below the matrix-core kernel's fill threshold)
-// amax (may be null; honoured by the 7x7 stride-1 kernels only - the ConvFFN's depthwise conv): see dwconv_tiled_kernel
+// amax (may be null; honoured by the stride-1 7x7 kernels - the ConvFFN's depthwise conv - and by the RepMixer 3x3): see dwconv_tiled_kernel
 extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const float* w, const float* bias,
                                   int B, int H, int W, int Cin, int K, int stride, int mult, int gelu, int batch_invariant, unsigned* amax)
 {
@@ -348,9 +348,11 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // Same arithmetic order: bit-identical outputs (tools/bench_ops.py dw3cfg, profiles/r02_dw3cfg.log).
     if (K == 3 && stride == 1 && mult == 1 && !gelu && c32 && g_dw3_cfg != 0) {
         const int cfg3 = g_dw3_cfg > 0 ? g_dw3_cfg : (c64 && Cin >= 192 ? 2 : 0);
-        if (cfg3 == 2 && c64) return (int)launch_dw_tiled<3, 1, 1, false, 64, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
-        if (cfg3 != 0) return (int)launch_dw_tiled<3, 1, 1, false, 32, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin);
+        if (cfg3 == 2 && c64) return (int)launch_dw_tiled<3, 1, 1, false, 64, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin, amax);
+        if (cfg3 != 0) return (int)launch_dw_tiled<3, 1, 1, false, 32, true, 3, 2>(st, xi, yo, w, bias, B, H, W, Cin, amax);
     }
+    if (K == 3 && stride == 1 && mult == 1 && !gelu && c32)
+        return (int)(c64 ? launch_dw_tiled<3, 1, 1, false, 64>(st, xi, yo, w, bias, B, H, W, Cin, amax) : launch_dw_tiled<3, 1, 1, false, 32>(st, xi, yo, w, bias, B, H, W, Cin, amax));
 #define DW_TILED(KK, SS, MM, AA)                                                                          \
     if (K == KK && stride == SS && mult == MM && (gelu != 0) == AA && c32) {                              \
         e = c64 ? launch_dw_tiled<KK, SS, MM, AA, 64>(st, xi, yo, w, bias, B, H, W, Cin)                  \

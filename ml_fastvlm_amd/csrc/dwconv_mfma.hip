@@ -66,12 +66,12 @@ template <int NW> struct DwmCfg {
 
 FVHD_DEV u16 f32_to_bf16_rne(float f) { unsigned u = __float_as_uint(f); u += 0x7fff + ((u >> 16) & 1); return (u16)(u >> 16); }
 
-template <int NW>
+template <int NW, bool AMAX>
 __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restrict__ x, u16* __restrict__ y, const float* __restrict__ w,
                                                               const float* __restrict__ bias, int H, int W, int C, int RC, int nstrip, int nchunk,
                                                               unsigned* amax)
 {
-    // amax (round 5, may be null): max |output| (fp32, before the rounding to bf16) over the rows this launch stores and the columns of its
+    // amax (round 5; AMAX instantiation only - the plain one carries none of the reduction's instructions): max |output| (fp32, before the rounding to bf16) over the rows this launch stores and the columns of its
     // strips (for W % 64 != 0 that includes up to 63 columns right of the image, computed from the zero padding: a superset, never less than
     // the image's own maximum), as the fp32 bit pattern of a non-negative number - the range guard of the half-precision fused ConvFFN
     using K = DwmCfg<NW>;
@@ -298,13 +298,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                 if (!(DWM_ABL & 2) && k >= 64 && k < 80) stage_write1(pk, ob, k - 64);
                 // max |.| of the finished row (its 16 accumulators: final since MFMA 59, pinned at k = 62), two v_max3_f32 per free slot;
                 // rows above the chunk (their slots hold partial sums and are never stored) do not count
-                if (k == 63) cand = 0.f;
-                if (k == 63 || (k >= 80 && k < 83)) {
+                if (AMAX && k == 63) cand = 0.f;
+                if (AMAX && (k == 63 || (k >= 80 && k < 83))) {
                     const int t = k == 63 ? 0 : k - 79;
                     cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t][0])), __builtin_fabsf(acc[u][t][1]));
                     cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t][2])), __builtin_fabsf(acc[u][t][3]));
                 }
-                if (k == 83) amx = (r - 3 >= ylo) ? __builtin_fmaxf(amx, cand) : amx;
+                if (AMAX && k == 83) amx = (r - 3 >= ylo) ? __builtin_fmaxf(amx, cand) : amx;
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = nslot;
@@ -327,10 +327,12 @@ done:
         for (int s7 = 0; s7 < 7; ++s7)
             if (s7 == sl) {
                 stage(acc[s7], ob);
+                if constexpr (AMAX) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) amx = __builtin_fmaxf(amx, __builtin_fabsf(acc[s7][t][i]));
+                        for (int i = 0; i < 4; ++i) amx = __builtin_fmaxf(amx, __builtin_fabsf(acc[s7][t][i]));
+                }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -340,7 +342,7 @@ done:
         ob ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the LDS is released
-    if (amax) {
+    if constexpr (AMAX) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
         if (lane == 0 && amx > 0.f) atomicMax(amax, __float_as_uint(amx));
@@ -373,14 +375,14 @@ static int dwm_rows_per_chunk(int B, int H, int W, int C)
     return 0;
 }
 
-template <int NW>
+template <int NW, bool AMAX>
 static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax)
 {
     static bool attr_set[64] = {};                           // per device (one process may drive several contexts)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)dw7_mfma_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, DwmCfg<NW>::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)dw7_mfma_kernel<NW, AMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, DwmCfg<NW>::LDS);
         if (e != hipSuccess) return (int)e;
         attr_set[dev & 63] = true;
     }
@@ -388,7 +390,7 @@ static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, co
     const int nstrip = (W + 63) / 64, nchunk = (H + RC - 1) / RC;
     const long long grid = (long long)B * (C / (16 * NW)) * nstrip * nchunk;
     if (grid <= 0 || grid > 0x7fffffffll) return (int)hipErrorInvalidValue;
-    dw7_mfma_kernel<NW><<<(int)grid, 64 * NW, DwmCfg<NW>::LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk, amax);
+    dw7_mfma_kernel<NW, AMAX><<<(int)grid, 64 * NW, DwmCfg<NW>::LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk, amax);
     return (int)hipGetLastError();
 }
 
@@ -406,5 +408,6 @@ extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force)
 extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax)
 {
     if (!fvhd_dw7_mfma_supported(B, H, W, C, 1)) return (int)hipErrorInvalidValue;
-    return C % 64 == 0 ? launch_dwm<4>(st, x, y, w, bias, B, H, W, C, amax) : launch_dwm<6>(st, x, y, w, bias, B, H, W, C, amax);
+    if (amax) return C % 64 == 0 ? launch_dwm<4, true>(st, x, y, w, bias, B, H, W, C, amax) : launch_dwm<6, true>(st, x, y, w, bias, B, H, W, C, amax);
+    return C % 64 == 0 ? launch_dwm<4, false>(st, x, y, w, bias, B, H, W, C, nullptr) : launch_dwm<6, false>(st, x, y, w, bias, B, H, W, C, nullptr);
 }

@@ -107,7 +107,10 @@ struct GemmW { size_t w = 0, b = 0; int N = 0, K = 0; bool has_bias = false; };
 // range: |fc1 out_j| <= sum_c |W1[j][c]| max|A| + |b1_j|, so max_j L1(W1 row j) * max|A| + max_j |b1_j| <= kGuardFc1Limit keeps every hidden
 // pre-activation at least a factor 2 below the 262 016 where gelu(x) / 4 saturates in IEEE half (the range guard, fvhd.h)
 struct FfnW { DwW dw7; GemmW fc1, fc2; size_t ls = 0; size_t w1img[2] = {0, 0}, w2img[2] = {0, 0}; bool fused = false; int precision = FVHD_FFN_HALF;
-              float guard_limit = 0.f; };
+              float guard_limit = 0.f, guard_limit_y = 0.f; };
+// guard_limit_y: the same guarantee one convolution earlier - a limit on max |y| of the block's dw7x7 INPUT (= the RepMixer output), through
+// |A_c| <= L1(folded 7x7 taps of channel c) max|y| + |folded bias_c|: looser by the taps' L1 norm, but max |y| can be reduced inside the
+// HBM-bound 3x3 kernel instead of the matrix-core 7x7 (FVHD_GUARD_SITE, fvhd.h "range guard")
 struct RepBlockW { DwW mixer; FfnW ffn; };
 struct AttnBlockW { size_t ln_w = 0, ln_b = 0, ls1 = 0; GemmW qkv, proj; FfnW ffn; };
 struct DownW { DwW dw; GemmW pw; };
@@ -131,6 +134,9 @@ struct Model {
 };
 
 struct ProfRec { int cls; hipEvent_t a, b; };
+#ifndef FVHD_GUARD_SITE_DEFAULT
+#define FVHD_GUARD_SITE_DEFAULT 1
+#endif
 constexpr float kGuardFc1Limit = 131072.0f;      // 2^17: half of the f16 saturation point of the fused kernel's hidden pre-activation
 constexpr int kGuardSlots = 4;                   // read-backs of the range guard in flight (one per encode call)
 struct GuardSlot { unsigned* host = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
@@ -169,6 +175,7 @@ struct fvhd_ctx {
     // range guard (round 5; fvhd.h "range guard"): every dw7x7 that feeds a half-precision fused ConvFFN reduces max |A| into guard_dev[step]
     // (zeroed per encode call); the array is read back asynchronously and compared with FfnW::guard_limit when the NEXT call polls it
     int guard_on = 1;
+    int guard_site = FVHD_GUARD_SITE_DEFAULT;    // 0: max |A| inside the dw7x7 (+BN) kernels, 1: max |y| inside the RepMixer dw3x3 kernel
     unsigned* guard_dev = nullptr;
     int guard_n = 0, guard_next = 0;
     GuardSlot guard_slots[kGuardSlots];
@@ -311,6 +318,20 @@ bool pack_ffn(fvhd_ctx* c, Packer& pk, const std::string& p, const std::string& 
         // (a 1 % allowance for the rounding of A to bf16 and of the fp32 accumulation is part of the factor 2 in kGuardFc1Limit)
         out->guard_limit = (!finite || b1max >= kGuardFc1Limit) ? -1.f : (l1max > 0.0 ? (float)((kGuardFc1Limit - b1max) / l1max) : INFINITY);
         if (out->guard_limit < 0.f) out->precision = FVHD_FFN_BF16;       // the biases alone leave the half-precision range: never on that form
+        // one convolution earlier: folded 7x7 taps w'[c][k] = w[c][k] s[c] and bias b'[c] (the values pack_dw uploads)
+        const HostTensor* w7 = find(c, p + ".convffn.conv.conv.weight", {C, 1, 7, 7});
+        if (!w7) return false;
+        double t7max = 0.0, b7max = 0.0;
+        for (int ch = 0; ch < C; ++ch) {
+            double l1 = 0.0;
+            for (int k = 0; k < 49; ++k) l1 += fabs((double)(w7->data[(size_t)ch * 49 + k] * s[ch]));
+            finite = finite && std::isfinite(l1) && std::isfinite(b[ch]);
+            t7max = l1 > t7max ? l1 : t7max;
+            b7max = fabs((double)b[ch]) > b7max ? fabs((double)b[ch]) : b7max;
+        }
+        if (out->guard_limit < 0.f || !finite) out->guard_limit_y = -1.f;
+        else if (!(out->guard_limit < INFINITY) || t7max == 0.0) out->guard_limit_y = (b7max <= out->guard_limit) ? INFINITY : 0.f;
+        else out->guard_limit_y = (float)fmax(0.0, ((double)out->guard_limit - b7max) / t7max);
         out->fused = true;
     }
     return pack_vec(c, pk, ls_key, {C, 1, 1}, &out->ls);
@@ -496,7 +517,7 @@ bool guard_check_slot(fvhd_ctx* c, const GuardSlot& sl)
         if (!f || !f->fused || f->precision != FVHD_FFN_HALF) continue;
         float a;
         memcpy(&a, &sl.host[i], 4);
-        if (!(a <= f->guard_limit)) {               // also NaN / Inf (they sort above every finite value in the reduction)
+        if (!(a <= (c->guard_site == 1 ? f->guard_limit_y : f->guard_limit))) {   // also NaN / Inf (they sort above every finite value in the reduction)
             f->precision = FVHD_FFN_BF16;
             c->guard_hits.push_back(GuardHit{i, a});
             switched = true;
@@ -562,7 +583,7 @@ int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, in
     int e;
     const bool take_fused = f.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows);
     // range guard: the depthwise conv that feeds a half-precision fused block also reduces max |A| into this step's slot
-    unsigned* amax = (c->guard_active && take_fused && f.precision == FVHD_FFN_HALF && step < c->guard_n) ? c->guard_dev + step : nullptr;
+    unsigned* amax = (c->guard_active && c->guard_site == 0 && take_fused && f.precision == FVHD_FFN_HALF && step < c->guard_n) ? c->guard_dev + step : nullptr;
     if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0, amax))) return e;
     if (c->audit_dev) {          // range audit: fc1 + bias as a plain GEMM into the hidden buffer, max |.| of it into this step's slot
         if ((e = run_gemm(c, st, C_FC1, c->wdev, f.fc1, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_BIAS))) return e;
@@ -623,9 +644,13 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
         return 0;
     case S_REP: {    // RepMixerBlock (mci.py:1106-1109)
         const RepBlockW& blk = m.rep[sp.stage][sp.idx];
-        if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0))) return e;
+        const int step = (int)(&sp - c->m.steps.data());
+        // range guard, site 1: the RepMixer's own output y is what the block's dw7x7 reads - max |y| into this step's slot
+        const bool fused_half = blk.ffn.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows) && blk.ffn.precision == FVHD_FFN_HALF;
+        unsigned* amax = (c->guard_active && c->guard_site == 1 && fused_half && step < c->guard_n) ? c->guard_dev + step : nullptr;
+        if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0, amax))) return e;
         std::swap(X, T);
-        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, (int)(&sp - c->m.steps.data()));
+        return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, step);
     }
     case S_ATT: {    // AttentionBlock (mci.py:1185-1188)
         const AttnBlockW& blk = m.att[sp.stage - 3][sp.idx];
@@ -696,7 +721,7 @@ int encode_body(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
 
     // ---- stem | graph of the interior steps | head ----
     if ((e = run_step(c, st, c->m.steps[0], w, X, T, B, images, img_dtype, nullptr, 0))) return e;
-    const int fkey = (int)c->use_fused_ffn | (c->batch_invariant << 1) | (c->attn_fp8 << 2) | ((int)c->guard_active << 3);
+    const int fkey = (int)c->use_fused_ffn | (c->batch_invariant << 1) | (c->attn_fp8 << 2) | ((int)c->guard_active << 3) | (c->guard_site << 4);
     fvhd_ctx::GraphEntry* g = nullptr;
     for (auto& q : c->graphs)
         if (q.B == B && q.fused == fkey && q.ws == c->ws) g = &q;
@@ -813,6 +838,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_GRAPH")) c->graph = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_RANGE_GUARD")) c->guard_on = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_GUARD_SITE")) c->guard_site = atoi(ev) != 0;
     *out = c;
     return 0;
 }
@@ -1096,7 +1122,7 @@ int fvhd_range_guard_limit(const fvhd_ctx* c, int step, float* limit_out)
 {
     const FfnW* f = ffn_of_step(const_cast<fvhd_ctx*>(c), step);
     if (!f || !f->fused || !limit_out) return fail("fvhd_range_guard_limit: step " + std::to_string(step) + " has no fused ConvFFN");
-    *limit_out = f->guard_limit;
+    *limit_out = c->guard_site == 1 ? f->guard_limit_y : f->guard_limit;      // the limit on the quantity the guard tracks (max |y| / max |A|)
     return 0;
 }
 

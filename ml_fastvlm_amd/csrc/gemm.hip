@@ -25,6 +25,7 @@
 //     8 x 8 super-tiles (see the kernel): every A / W panel fetched from HBM feeds 8 resident tiles.
 #include "fvhd_common.h"
 #include "gemm_layout.h"
+#include <stdlib.h>
 
 #define EPI_NONE 0
 #define EPI_BIAS 1
@@ -55,7 +56,10 @@ FVHD_DEV int lds_off(int row, int ks)
 // (EpiGrp, wrow_of_lds_row, wpiece_row, wpiece_lane_row, epi_col: gemm_layout.h - shared with the CPU test of the mapping)
 // ---- epilogue of one wave's (16 MF) x (16 NF) block.  GRP = 1: lane holds out[m][n .. n+3], m = mw + 16 i + lr, n = nw + 16 j + 4 g;
 // GRP = 2 / 4: out[m][n .. n + 4 GRP - 1], n = nw + 16 GRP jb + 4 GRP g, as acc[i][GRP jb .. GRP jb + GRP - 1]
-template <int MF, int NF, int EPI, int ODT>
+// ROWMAJOR (the streaming kernels, whose occupancy the LDS ring fixes at one workgroup per CU): rows outermost, see below; the register-
+// prefetch kernel v1 keeps the column groups outermost - the preloaded bias / layer-scale vectors of the row-major walk would take its
+// GELU / residual variants from 168 to 174-178 registers, i.e. from three resident workgroups to two
+template <int MF, int NF, int EPI, int ODT, bool ROWMAJOR = false>
 FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias, const float* __restrict__ ls, const bf16* resid, void* out,
                             int M, int N, int mw, int nw, int lr, int g)
 {
@@ -97,54 +101,71 @@ FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias
         }
     } else {
         static_assert(ODT == FVHD_BF16 && NF % GRP == 0, "grouped epilogue: bf16 outputs");
-#pragma unroll
-        for (int jb = 0; jb < NF / GRP; ++jb) {
-            const int n = nw + epi_col<GRP>(jb, g);
-            if (n >= N) continue;
-            f32x4 bv[GRP], lv[GRP];
+        // Row-major walk (i outer, column groups inner): a wave writes the 64-B segments of one 128-B line of its block back to back.  With
+        // the groups outermost (first version of this epilogue) the second half of a line followed MF GELU blocks later and the L2 evicted
+        // half-written lines in between: WRITE_SIZE stayed at 1.18-1.31x the algorithmic bytes (profiles/r05_gemm_layout.md).
+        constexpr int NJB = NF / GRP;
+        f32x4 bv[NJB][GRP], lv[NJB][GRP];
+        int ncol[NJB];
+        auto load_vectors = [&](int jb) {                          // bias / layer scale of column group jb
+            ncol[jb] = nw + epi_col<GRP>(jb, g);
+            const int nn = ncol[jb] < N ? ncol[jb] : 0;            // (columns past N are never stored: any valid address for the vectors)
 #pragma unroll
             for (int c = 0; c < GRP; ++c) {
-                bv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                lv[c] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_LS_RESID) bv[c] = *(const f32x4*)(bias + n + 4 * c);
-                if constexpr (EPI == EPI_BIAS_LS_RESID) lv[c] = *(const f32x4*)(ls + n + 4 * c);
+                bv[jb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                lv[jb][c] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_LS_RESID) bv[jb][c] = *(const f32x4*)(bias + nn + 4 * c);
+                if constexpr (EPI == EPI_BIAS_LS_RESID) lv[jb][c] = *(const f32x4*)(ls + nn + 4 * c);
             }
+        };
+        auto emit = [&](int i, int jb) {                           // rows m = mw + 16 i + lr, columns ncol[jb] .. + 4 GRP - 1
+            const int m = mw + i * 16 + lr, n = ncol[jb];
+            if (m >= M || n >= N) return;
+            f32x4 v[GRP];
 #pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const int m = mw + i * 16 + lr;
-                if (m >= M) continue;
-                f32x4 v[GRP];
+            for (int c = 0; c < GRP; ++c) v[c] = acc[i][jb * GRP + c] + bv[jb][c];
+            if constexpr (EPI == EPI_SWIGLU) {
+                // 16 consecutive columns = (gate, up) of the 8 hidden units n/2 .. n/2 + 7: one 16-B store into the [M, N/2] activation
+                static_assert(EPI != EPI_SWIGLU || GRP == 4, "SwiGLU: four fragments per group");
+                f32x8 r;
 #pragma unroll
-                for (int c = 0; c < GRP; ++c) v[c] = acc[i][jb * GRP + c] + bv[c];
-                if constexpr (EPI == EPI_SWIGLU) {
-                    // 16 consecutive columns = (gate, up) of the 8 hidden units n/2 .. n/2 + 7: one 16-B store into the [M, N/2] activation
-                    static_assert(GRP == 4, "SwiGLU: four fragments per group");
-                    f32x8 r;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        r[2 * c] = v[c][0] * sigmoidf_fast(v[c][0]) * v[c][1];
-                        r[2 * c + 1] = v[c][2] * sigmoidf_fast(v[c][2]) * v[c][3];
-                    }
-                    *(bf16x8*)((bf16*)out + (size_t)m * (N / 2) + n / 2) = f32_to_bf8(r);
-                    continue;
-                } else {
-                    static_assert(EPI == EPI_SWIGLU || GRP == 2, "bf16 rows: two fragments per group");
-                    if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                        for (int c = 0; c < GRP; ++c)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[c][e] = gelu_erf(v[c][e]);
-                    }
-                    const size_t o = (size_t)m * N + n;
-                    if constexpr (EPI == EPI_BIAS_LS_RESID || EPI == EPI_RESID) {
-                        const bf16x8 rr = *(const bf16x8*)(resid + o);
-                        const f32x4 r0 = bf4_to_f32(__builtin_shufflevector(rr, rr, 0, 1, 2, 3)), r1 = bf4_to_f32(__builtin_shufflevector(rr, rr, 4, 5, 6, 7));
-                        v[0] = r0 + lv[0] * v[0];
-                        v[1] = r1 + lv[1] * v[1];
-                    }
-                    const bf16x4 b0 = f32_to_bf4(v[0]), b1 = f32_to_bf4(v[1]);
-                    *(bf16x8*)((bf16*)out + o) = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int c = 0; c < GRP; ++c) {
+                    r[(2 * c) & 7] = v[c][0] * sigmoidf_fast(v[c][0]) * v[c][1];
+                    r[(2 * c + 1) & 7] = v[c][2] * sigmoidf_fast(v[c][2]) * v[c][3];
                 }
+                *(bf16x8*)((bf16*)out + (size_t)m * (N / 2) + n / 2) = f32_to_bf8(r);
+            } else {
+                static_assert(EPI == EPI_SWIGLU || GRP == 2, "bf16 rows: two fragments per group");
+                if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int c = 0; c < GRP; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[c][e] = gelu_erf(v[c][e]);
+                }
+                const size_t o = (size_t)m * N + n;
+                if constexpr (EPI == EPI_BIAS_LS_RESID || EPI == EPI_RESID) {
+                    const bf16x8 rr = *(const bf16x8*)(resid + o);
+                    const f32x4 r0 = bf4_to_f32(__builtin_shufflevector(rr, rr, 0, 1, 2, 3)), r1 = bf4_to_f32(__builtin_shufflevector(rr, rr, 4, 5, 6, 7));
+                    v[0] = r0 + lv[jb][0] * v[0];
+                    v[1] = r1 + lv[jb][1] * v[1];
+                }
+                const bf16x4 b0 = f32_to_bf4(v[0]), b1 = f32_to_bf4(v[1]);
+                *(bf16x8*)((bf16*)out + o) = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        };
+        if constexpr (ROWMAJOR) {
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) load_vectors(jb);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int jb = 0; jb < NJB; ++jb) emit(i, jb);
+        } else {
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) {
+                load_vectors(jb);                                  // one group's vectors live at a time
+#pragma unroll
+                for (int i = 0; i < MF; ++i) emit(i, jb);
             }
         }
     }
@@ -297,13 +318,22 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, g = lane >> 4;
-    const int L = xcd_remap(blockIdx.x, nwg);               // same super-tile order as v1 (8 x 8 tiles share their panels in one XCD's L2)
+    // Tile t of the launch (same super-tile order as v1: 8 x 8 tiles share their panels in one XCD's L2).  PERSISTENT form (round 5): with
+    // gridDim.x < nwg a workgroup walks the tiles t = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8, so a tile stays on the XCD
+    // the one-tile-per-workgroup launch would have given it) and issues the first K tiles of its NEXT tile before the epilogue of the
+    // current one: the DMA round trip and the workgroup hand-over of a fresh launch slot hide behind the stores.  gridDim.x == nwg is the
+    // one-tile form of rounds 2-4, unchanged.
     constexpr int GN = BN == 256 ? 4 : 8;
     const int tiles_m = nwg / tiles_n;
-    const int grp = L / (tiles_m * GN), rem = L - grp * tiles_m * GN;
-    const int wg = min(GN, tiles_n - grp * GN);
-    const int tm = rem / wg, tn = grp * GN + (rem - tm * wg);
-    const int m0 = tm * BM, n0 = tn * BN;
+    auto tile_origin = [&](int t, int& m0_, int& n0_) {
+        const int L = xcd_remap(t, nwg);
+        const int grp = L / (tiles_m * GN), rem = L - grp * tiles_m * GN;
+        const int wg = min(GN, tiles_n - grp * GN);
+        const int tm = rem / wg, tn = grp * GN + (rem - tm * wg);
+        m0_ = tm * BM; n0_ = tn * BN;
+    };
+    int tile = blockIdx.x, m0, n0;
+    tile_origin(tile, m0, n0);
 
     // per-lane global byte offsets of this wave's pieces: rows 8 p + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7); the swizzle
     // term depends on the piece's parity only, the row base of a piece goes into the scalar base
@@ -322,7 +352,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
     const char* abase = (const char*)(A + (size_t)(m0 + wave * RPP * PA) * K);   // A pieces PA wave .. PA wave + PA - 1 = rows RPP PA wave ..
     const char* wbase = (const char*)(Wt + (size_t)n0 * K);
     const unsigned lds0 = lds_addr(lds2);
-    auto issue = [&](int kt) {
+    auto issue = [&](int kt) {                                 // K tile kt of the tile abase / wbase point at
         if constexpr (ABL == 1) return;
         const unsigned st = lds0 + (kt % RS) * STAGE;
         const size_t ko = (size_t)kt * BK * 2;
@@ -336,18 +366,21 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
         }
     };
 
+    const int nk = K / BK;
+#pragma unroll
+    for (int i = 0; i < RS - 1; ++i)
+        if (i < nk) issue(i);
+  for (;;) {
     f32x4 acc[MF][NF];
 #pragma unroll
     for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
-#pragma unroll
-    for (int i = 0; i < RS - 1; ++i)
-        if (i < nk) issue(i);
     for (int kt = 0; kt < nk; ++kt) {
-        // own pieces of tile kt have landed when at most the RS - 2 later tiles' PA + PW are outstanding (loads only in this loop)
+        // own pieces of tile kt have landed when at most the RS - 2 later tiles' PA + PW are outstanding.  (vmcnt <= n means at most n
+        // operations are outstanding, and loads return in order: whatever else is in flight - the previous tile's epilogue stores in
+        // the persistent form - all but the youngest n LOADS have landed.)
         // (near the end fewer later tiles exist: RS - 2 only while kt + RS - 2 < nk)
         {
             const int later = nk - 1 - kt < RS - 2 ? nk - 1 - kt : RS - 2;
@@ -381,7 +414,21 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 && BKT == 32) ? 2 : 1) void gem
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 16 * MF, n0 + wn * 64, lr, g);
+    const int em0 = m0 + wm * 16 * MF, en0 = n0 + wn * 64;
+    tile += gridDim.x;
+    const bool more = tile < nwg;                              // workgroup-uniform
+    if (more) {
+        __syncthreads();                                       // every wave has read the last K tile: all stages are free
+        tile_origin(tile, m0, n0);
+        abase = (const char*)(A + (size_t)(m0 + wave * RPP * PA) * K);
+        wbase = (const char*)(Wt + (size_t)n0 * K);
+#pragma unroll
+        for (int i = 0; i < RS - 1; ++i)
+            if (i < nk) issue(i);                              // the next tile's first K tiles fly during this tile's epilogue
+    }
+    gemm_epilogue<MF, NF, EPI, ODT, true>(acc, bias, ls, resid, out, M, N, em0, en0, lr, g);
+    if (!more) break;
+  }
 }
 
 // v1s (round 4): v1's 128 x 128 tile / 4 waves (2 x 2, 64 x 64 each) with the operands streamed by LDS-DMA through a FOUR-stage ring of 32-KB
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void gemm128s_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + wm * 64, n0 + wn * 64, lr, g);
+    gemm_epilogue<MF, NF, EPI, ODT, true>(acc, bias, ls, resid, out, M, N, m0 + wm * 64, n0 + wn * 64, lr, g);
 }
 
 // v4 (round 3, experiment): "ping-pong" 256 x 256 tile.  The 8 waves form two groups (rows 0-127 / 128-255 of the tile; one wave of each
@@ -592,7 +639,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();             // group 0 matches group 1's extra phase
 #undef PP_END
-    gemm_epilogue<MF, NF, EPI, ODT>(acc, bias, ls, resid, out, M, N, m0 + grp * 128, n0 + wn * 64, lr, g);
+    gemm_epilogue<MF, NF, EPI, ODT, true>(acc, bias, ls, resid, out, M, N, m0 + grp * 128, n0 + wn * 64, lr, g);
+}
+
+#ifndef FVHD_GEMM_PERSIST_DEFAULT
+#define FVHD_GEMM_PERSIST_DEFAULT 0     // the streaming 256 x (128 | 256) kernels as persistent workgroups (measured in profiles/r05_gemm_persist.log)
+#endif
+// Compute units of the current device (round 5, advisor: the dispatch rules below were written as multiples of MI355X's 256 CUs; a
+// partitioned mode - CPX / DPX - or another part changes the count, and with it where "one round of tiles" ends).  Kernel choice only:
+// every kernel gives identical bits.
+static int cu_count()
+{
+    static int cached[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& n = cached[dev & 63];
+    if (n <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
 }
 
 #ifdef FVHD_DEBUG_KNOBS                 // A/B runs (tools/bench_ops.py gemm on libfvhd_ablate.so): 0 = always the v1 kernel
@@ -616,7 +683,14 @@ static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, 
     }
     const int tiles_m = M / 256, tiles_n = N / BN, nwg = tiles_m * tiles_n;
     constexpr int LDSB = G2Cfg<BN, BKT, NWV>::LDS;
-    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN, BKT, ABL>), dim3(nwg), dim3(64 * NWV), LDSB, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
+    // persistent form (one workgroup per CU walks the tiles, see the kernel): FVHD_GEMM_PERSIST=1 / 0 in the environment overrides the default
+    static const int persist = [] { const char* ev = getenv("FVHD_GEMM_PERSIST"); return ev ? atoi(ev) : FVHD_GEMM_PERSIST_DEFAULT; }();
+    int grid = nwg;
+    if (persist && ABL == 0) {
+        const int g8 = cu_count() & ~7;                        // a multiple of the 8 XCDs: tile t stays on XCD t % 8
+        if (g8 >= 8 && nwg > g8) grid = g8;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<EPI, ODT, NWV, BN, BKT, ABL>), dim3(grid), dim3(64 * NWV), LDSB, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg);
     return hipGetLastError();
 }
 
@@ -707,23 +781,6 @@ static hipError_t dispatch_gemm128s(hipStream_t st, const bf16* a, const bf16* w
 // down_proj 63.4 -> 52.6, the tower at B = 1: stage-2 fc2 24.6 -> 21.3, stage-4 qkv / fc1 22.0 / 24.9 -> 19.0 / 21.5 - behind it from ~300 on
 // (v1 then has 2-4 workgroups per CU covering each other's latency: stage-2 fc1 at B = 1, 384 tiles, 16.1 -> 21.0), and behind v1 for the
 // slices of a split-K launch with 250-500 workgroups (llm down / 4: 39.7 -> 43.0)
-// Compute units of the current device (round 5, advisor: the dispatch rules below were written as multiples of MI355X's 256 CUs; a
-// partitioned mode - CPX / DPX - or another part changes the count, and with it where "one round of tiles" ends).  Kernel choice only:
-// every kernel gives identical bits.
-static int cu_count()
-{
-    static int cached[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int& n = cached[dev & 63];
-    if (n <= 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n = v;
-    }
-    return n;
-}
-
 #ifndef FVHD_GEMM128S_ROUNDS
 #define FVHD_GEMM128S_ROUNDS 1             // v1s is taken up to this many workgroups per CU in one launch (0 = never): one round of one workgroup per CU
 #endif

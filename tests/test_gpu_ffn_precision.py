@@ -140,12 +140,14 @@ def _hot_weights_state_dict():
     x = synth.synthetic_images(2, 256, seed=5)
     probe = _tower(synth.synthetic_state_dict(1234, "mild"), mm_vision_ffn_precision="half")
     rep = [r for r in probe.audit_ranges(x.to(DEV)) if (r["stage"], r["block"]) == (1, 3)][0]
-    k = int(torch.ceil(torch.log2(torch.tensor(1.0e6 / rep["max_abs_fc1"]))).item())
+    # 3e7: the TYPICAL hidden unit of the block (a tenth of the maximum) is then an order of magnitude beyond the 262 016 where the half
+    # form saturates - most of the block's output is lost there, not just its hottest unit (a 1e6 peak moved the tower's rel-L2 by 2 %)
+    k = int(torch.ceil(torch.log2(torch.tensor(3.0e7 / rep["max_abs_fc1"]))).item())
     return _scaled_block_state_dict(k), x, rep["max_abs_fc1"] * 2.0 ** k
 
 
 def test_the_default_configuration_is_range_safe_on_the_first_call():
-    """No option given (VERDICT r4 item 3): "auto" + the range guard.  The weight-driven checkpoint reaches ~1e6 in one block's fc1 output;
+    """No option given (VERDICT r4 item 3): "auto" + the range guard.  The weight-driven checkpoint reaches ~3e7 in one block's fc1 output;
     the very first call must already be inside the whole-tower tolerance, and the half form forced onto that block must not be."""
     sd, x, peak = _hot_weights_state_dict()
     want = O.tower_forward(x, sd)
@@ -184,7 +186,7 @@ def test_range_guard_catches_an_image_hotter_than_the_calibration_batch():
     tower = _tower(sd, mm_vision_ffn_precision="half")
     ctx, hot = tower._context(), _hot_step(tower)
     lim = ctx.range_guard_limit(hot)
-    assert 0.0 < lim < 100.0, lim                                    # the scaled fc1 rows leave little room for max|A|
+    assert 0.0 <= lim < 100.0, lim                                   # the scaled fc1 rows leave (next to) no room for the tracked maximum
     assert ctx.ffn_precision(hot) == _lib.FFN_HALF
     first = tower(xd).float().cpu()                                  # computed on the half form: saturated
     torch.cuda.synchronize()

@@ -208,10 +208,11 @@ def test_drop_in_defaults_are_range_safe_on_a_saturating_checkpoint():
     from llava.model.language_model.llava_qwen import LlavaQwen2ForCausalLM
     saved = (enc_builder.build_vision_tower, arch.build_vision_tower, arch.LlavaMetaForCausalLM.encode_images)
     hidden = 128
-    # stage 1, block 3: fc1.weight x 2^22, layer scale x 2^-22 (tests/test_gpu_ffn_precision.py: hidden pre-activations ~1.6e6 on these images)
+    # stage 1, block 3: fc1.weight x 2^27, layer scale x 2^-27 (tests/test_gpu_ffn_precision.py: hidden pre-activations up to ~5e7 on these
+    # images, the typical unit an order of magnitude beyond the half form's 262 016)
     tower_sd = synth.synthetic_state_dict(1234, "mild")
-    tower_sd["network.2.3.convffn.fc1.weight"] *= 2.0 ** 22
-    tower_sd["network.2.3.layer_scale"] *= 2.0 ** -22
+    tower_sd["network.2.3.convffn.fc1.weight"] *= 2.0 ** 27
+    tower_sd["network.2.3.layer_scale"] *= 2.0 ** -27
     proj_sd = synth.synthetic_projector_state_dict(hidden, 1234)
     images = synth.synthetic_images(2, 256, seed=5).to(DEV)
     try:

@@ -126,6 +126,36 @@ PY
         grep -i "gemm\|class" ${O}_${lib}_write_summary.md | cut -c1-220
     done
     ;;
+r5b)        # round 5, second call: the tests the first call failed / the kernels touched since, guard-site and persistent-GEMM A/B on one box, WRITE_SIZE again
+    timeout 900 python -m pytest tests/test_gpu_ffn_precision.py tests/test_gpu_ops.py tests/test_qwen2_prefill.py tests/test_gpu_steps.py "tests/test_gpu_reference.py::test_drop_in_defaults_are_range_safe_on_a_saturating_checkpoint" -m gpu -q --maxfail=20 --durations=5 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-300
+    run_bench() { # label, env...
+        local label=$1; shift
+        env "$@" timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_${label}.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_${label}.json")); print("${label}", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("gemm") or k in ("projector", "dw7", "dw3", "ffn_fused")})
+PY
+    }
+    run_bench guard_off FVHD_RANGE_GUARD=0
+    run_bench guard_dw7 FVHD_GUARD_SITE=0
+    run_bench guard_dw3 FVHD_GUARD_SITE=1
+    run_bench persist FVHD_GUARD_SITE=1 FVHD_GEMM_PERSIST=1
+    run_bench guard_off2 FVHD_RANGE_GUARD=0
+    for v in "base FVHD_GEMM_PERSIST=0" "persist FVHD_GEMM_PERSIST=1" "g1 FVHD_LIB=ml_fastvlm_amd/libfvhd_g1.so"; do
+        set -- $v
+        env $2 timeout 300 python bench.py --ttft --steps 10 --warmup 2 > ${O}_ttft_$1.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_ttft_$1.json")); c=d["config"]; print("ttft $1", d["value"], c["encode_images_ms"], c["splice_ms"], c["prefill_first_token_ms"], c["prefill_roofline"]["frac"])
+PY
+    done
+    CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-ttft"
+    for pass in trace write; do
+        extra=""; [ "$pass" = write ] && extra="--pmc WRITE_SIZE"
+        timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_${pass} -o ${pass} $extra -- $CMD > gpurun_out/${TAG}_${pass}.log 2>&1
+    done
+    python tools/pmc_summary.py ${TAG}_w gpurun_out/${TAG}_trace gpurun_out/${TAG}_write > ${O}_write_summary.md 2>${O}_write_summary.err
+    rm -f profiles/${TAG}_w_pmc_summary.json; rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_write
+    grep -i "gemm\|class" ${O}_write_summary.md | cut -c1-200
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;
