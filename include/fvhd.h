@@ -132,10 +132,11 @@ int fvhd_audit_ranges(fvhd_ctx* ctx, const void* images, int img_dtype, int batc
  * the guarantee per batch poll with wait = 1 after the call and re-encode when a step is reported (the Python tower does exactly that
  * when mm_vision_range_guard = "strict").  Inactive while the caller's stream is being captured (an event inside a graph cannot be
  * polled): graph-capturing callers calibrate with fvhd_audit_ranges first.
- * WHERE the maximum is taken (FVHD_GUARD_SITE in the environment of fvhd_create; default 1): 0 = max |A| inside the dw7x7 (+BN) kernel, limit as
- * above; 1 = one convolution earlier, max |y| of the RepMixer output inside the HBM-bound dw3x3 kernel, with |A_c| <= L1(folded 7x7 taps of c)
- * max|y| + |folded BN bias_c|, i.e. limit_y = (limit - max_c |bias_c|) / max_c L1(taps_c): a looser bound (by the 7x7 taps' L1 norm, 2-5x) for
- * a reduction that costs nothing measurable (profiles/r05_guard_site.log; site 0 cost ~5 % of the matrix-core dw7x7 kernel).
+ * WHERE the maximum is taken (FVHD_GUARD_SITE in the environment of fvhd_create; default 0): 0 = max |A| inside the dw7x7 (+BN) kernel, limit as
+ * above; 1 = one convolution earlier, max |y| of the RepMixer output inside the dw3x3 kernel, with |A_c| <= L1(folded 7x7 taps of c) max|y| +
+ * |folded BN bias_c|, i.e. limit_y = (limit - max_c |bias_c|) / max_c L1(taps_c) - a looser bound (by the 7x7 taps' L1 norm, 2-5x).  Measured
+ * on one box, whole step at B = 32 (profiles/r05_guard_site_persist_ab.log): site 0 24.26 ms, site 1 24.53, guard off 24.52 / 24.51 - the reduction costs
+ * the matrix-core dw7x7 class 5 % (3.54 -> 3.72 ms) and the step nothing.
  *   fvhd_set_range_guard(ctx, 0 / 1)   - default 1 (environment: FVHD_RANGE_GUARD=0).
  *   fvhd_range_guard_limit             - the limit on the tracked maximum (max|A| / max|y|) of a fused step (INFINITY if the weights are all
  *                                        zero, < 0 if the block can never run the half form).

@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     // amax (round 5, may be null): max |output| over everything this launch stores, as the fp32 bit pattern of a non-negative number
     // (atomicMax on unsigned = numeric max) - the range guard of the half-precision fused ConvFFN reads it (fvhd_api.hip: run_ffn)
     using T = DwTile<K, S, MULT, ACT, CS, OW4>;
+    // the reduction is compiled into the stride-1 / multiplier-1 / no-activation instantiations only (RepMixer 3x3, ConvFFN 7x7): the other
+    // shapes never get a pointer, and their register budgets (PatchEmbed 7x7 / s2 at 168) have no room to carry it for nothing
+    constexpr bool AMAXK = S == 1 && MULT == 1 && !ACT;
     constexpr int PAD = T::PAD, CSI = T::CSI, LPP = T::LPP, LPI = T::LPI, OWT = T::OWT, TW = T::TW, TH = T::TH;
     constexpr int IW = T::IW, IWP = T::IWP, NIN = T::NIN, CI = T::CI, NLD = T::NLD, IH_ = T::IH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                 for (int c = 0; c < 8; ++c) rr[c] = ACT ? gelu_erf(acc[o][c]) : acc[o][c];
                 *(bf16x8*)(yo + (size_t)o * Cout) = f32_to_bf8(rr);
-                if (amax) {                                     // wave-uniform; v_max3_f32 with |.| modifiers: 4 VALU per 8 outputs
+                if (AMAXK && amax) {                            // wave-uniform; v_max3_f32 with |.| modifiers: 4 VALU per 8 outputs
 #pragma unroll
                     for (int c = 0; c < 8; c += 2) amx = __builtin_fmaxf(__builtin_fmaxf(amx, __builtin_fabsf(rr[c])), __builtin_fabsf(rr[c + 1]));
                 }
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
         if constexpr (!DMA) __syncthreads();   // every wave is done reading the LDS tile before the next one overwrites it
     }
-    if (amax) {
+    if (AMAXK && amax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
         if ((tid & 63) == 0 && amx > 0.f) atomicMax(amax, __float_as_uint(amx));

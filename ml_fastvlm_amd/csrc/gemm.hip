@@ -59,11 +59,17 @@ FVHD_DEV int lds_off(int row, int ks)
 // ROWMAJOR (the streaming kernels, whose occupancy the LDS ring fixes at one workgroup per CU): rows outermost, see below; the register-
 // prefetch kernel v1 keeps the column groups outermost - the preloaded bias / layer-scale vectors of the row-major walk would take its
 // GELU / residual variants from 168 to 174-178 registers, i.e. from three resident workgroups to two
-template <int MF, int NF, int EPI, int ODT, bool ROWMAJOR = false>
+// (-DFVHD_GEMM_EPI_COLMAJOR: the column-group-outermost walk everywhere, for same-box A/B runs: FVHD_VARIANT_TAG=cm)
+template <int MF, int NF, int EPI, int ODT, bool ROWMAJOR_ = false>
 FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias, const float* __restrict__ ls, const bf16* resid, void* out,
                             int M, int N, int mw, int nw, int lr, int g)
 {
     constexpr int GRP = EpiGrp<NF, EPI, ODT>::value;
+#ifdef FVHD_GEMM_EPI_COLMAJOR
+    constexpr bool ROWMAJOR = false;
+#else
+    constexpr bool ROWMAJOR = ROWMAJOR_;
+#endif
     if constexpr (GRP == 1) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) {

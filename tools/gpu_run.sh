@@ -156,6 +156,29 @@ PY
     rm -f profiles/${TAG}_w_pmc_summary.json; rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_write
     grep -i "gemm\|class" ${O}_write_summary.md | cut -c1-200
     ;;
+r5c)        # round 5, third call: the two range tests again, epilogue walk A/B (libfvhd_cm.so), the dw3 / dw7 coupling per stage (kernel traces)
+    timeout 600 python -m pytest tests/test_gpu_ffn_precision.py "tests/test_gpu_reference.py::test_drop_in_defaults_are_range_safe_on_a_saturating_checkpoint" tests/test_gpu_ops.py -k "not gemm and not attention and not ffn_fused" -m gpu -q --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -12 ${O}_pytest.log | cut -c1-300
+    run_bench() { # label, env...
+        local label=$1; shift
+        env "$@" timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_${label}.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_${label}.json")); print("${label}", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("gemm") or k in ("projector", "dw7", "dw3", "ffn_fused")})
+PY
+    }
+    run_bench rowmajor FVHD_LIB=ml_fastvlm_amd/libfvhd.so
+    run_bench colmajor FVHD_LIB=ml_fastvlm_amd/libfvhd_cm.so
+    run_bench rowmajor2 FVHD_LIB=ml_fastvlm_amd/libfvhd.so
+    run_bench colmajor2 FVHD_LIB=ml_fastvlm_amd/libfvhd_cm.so
+    run_bench guard_off FVHD_RANGE_GUARD=0
+    CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-ttft"
+    for mode in site0 off; do
+        g=1; [ "$mode" = off ] && g=0
+        FVHD_RANGE_GUARD=$g timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_tr_${mode} -o tr -- $CMD > gpurun_out/${TAG}_tr_${mode}.log 2>&1
+        python tools/rocpd_by_grid.py gpurun_out/${TAG}_tr_${mode}/tr_results.db dwconv_tiled dw7_mfma ffn_fused > ${O}_bygrid_${mode}.md 2>&1
+        rm -rf gpurun_out/${TAG}_tr_${mode}
+        echo "--- $mode"; cat ${O}_bygrid_${mode}.md | cut -c1-170
+    done
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;
