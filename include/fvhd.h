@@ -212,11 +212,13 @@ int fvhd_op_dwconv(fvhd_stream_t stream, const void* x, void* y, const float* w,
  * the chip (or always, under fvhd_set_batch_invariant).  Same arguments as fvhd_op_dwconv(K = 7, stride 1, mult 1, no GELU);
  * needs C % 64 == 0 or C % 96 == 0 and W >= 16, anything else is an error. */
 int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C);
-/* The same convolution with the range guard's reduction (round 5): amax_bits (device, 4 bytes, zeroed by the caller) receives max |y| - over
+/* The same convolution with the range guard's reduction (round 5): amax_bits (device, FVHD_AMAX_SLOTS = 64 32-bit words, zeroed by the caller; the
+ * workgroups spread their atomics over the words, the result is the maximum of all 64) receives max |y| - over
  * everything the launch stores (VALU kernel, mfma = 0) or over the stored rows and the columns of the kernel's 64-px strips (matrix-core kernel,
  * mfma = 1: for W % 64 != 0 a superset of the image, computed from the zero padding) - as the fp32 bit pattern of a non-negative number
  * (combined with atomicMax: unsigned order = numeric order), taken from the fp32 accumulators before the rounding to bf16.  mfma = 0 is an error
  * for shapes the dispatcher gives to the matrix-core kernel, mfma = 1 for shapes that kernel does not take. */
+#define FVHD_AMAX_SLOTS 64
 int fvhd_op_dw7_amax(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, int mfma,
                      void* amax_bits);
 /* out[M,N] = epi(A[M,K] . Wt[N,K]^T): A, Wt, resid bf16; bias, ls fp32 [N]; K % 32 == 0, N % 16 == 0.  out_dtype other than bf16 only with

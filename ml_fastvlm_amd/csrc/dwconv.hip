@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
     int B, int H, int W, int Cin, int OH, int OW, int tiles_x, int tiles_y, int nslices, int ntiles, int dbg_mode, unsigned* amax)
 {
-    // amax (round 5, may be null): max |output| over everything this launch stores, as the fp32 bit pattern of a non-negative number
-    // (atomicMax on unsigned = numeric max) - the range guard of the half-precision fused ConvFFN reads it (fvhd_api.hip: run_ffn)
+    // amax (round 5, may be null): max |output| over everything this launch stores, as fp32 bit patterns of non-negative numbers (atomicMax
+    // on unsigned = numeric max) in a row of FVHD_AMAX_SLOTS words - the range guard of the half-precision fused ConvFFN reads it (fvhd_api.hip: run_ffn)
     using T = DwTile<K, S, MULT, ACT, CS, OW4>;
     // the reduction is compiled into the stride-1 / multiplier-1 / no-activation instantiations only (RepMixer 3x3, ConvFFN 7x7): the other
     // shapes never get a pointer, and their register budgets (PatchEmbed 7x7 / s2 at 168) have no room to carry it for nothing
@@ -257,10 +257,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
         if constexpr (!DMA) __syncthreads();   // every wave is done reading the LDS tile before the next one overwrites it
     }
-    if (AMAXK && amax) {
+    if (AMAXK && amax) {                        // (wave-uniform) wave -> workgroup through LDS -> one atomic per workgroup, slot by block id
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
-        if ((tid & 63) == 0 && amx > 0.f) atomicMax(amax, __float_as_uint(amx));
+        __syncthreads();                        // every wave is done with the tile buffers
+        float* red = (float*)smem;
+        if ((tid & 63) == 0) red[tid >> 6] = amx;
+        __syncthreads();
+        if (tid == 0) {
+            const float m = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+            if (m > 0.f) atomicMax(amax + (blockIdx.x % FVHD_AMAX_SLOTS), __float_as_uint(m));
+        }
     }
 }
 

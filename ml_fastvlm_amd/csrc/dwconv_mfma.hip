@@ -73,7 +73,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
 {
     // amax (round 5; AMAX instantiation only - the plain one carries none of the reduction's instructions): max |output| (fp32, before the rounding to bf16) over the rows this launch stores and the columns of its
     // strips (for W % 64 != 0 that includes up to 63 columns right of the image, computed from the zero padding: a superset, never less than
-    // the image's own maximum), as the fp32 bit pattern of a non-negative number - the range guard of the half-precision fused ConvFFN
+    // the image's own maximum), as fp32 bit patterns of non-negative numbers in a row of FVHD_AMAX_SLOTS words (fvhd_common.h) - the range
+    // guard of the half-precision fused ConvFFN
     using K = DwmCfg<NW>;
     constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = DWM_RS, P = DWM_P, OPX = K::OPX, RAWB = K::RAWB, OB = K::OB, TBY = K::TB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -342,10 +343,19 @@ done:
         ob ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the LDS is released
-    if constexpr (AMAX) {
+    if constexpr (AMAX) {                                   // wave -> workgroup (through LDS) -> one atomic per workgroup, slot by block id
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
-        if (lane == 0 && amx > 0.f) atomicMax(amax, __float_as_uint(amx));
+        __syncthreads();                                    // every wave is done with the staging buffers
+        float* red = (float*)smem;
+        if (lane == 0) red[wv] = amx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = red[0];
+#pragma unroll
+            for (int i = 1; i < NW; ++i) m = __builtin_fmaxf(m, red[i]);
+            if (m > 0.f) atomicMax(amax + (blockIdx.x % FVHD_AMAX_SLOTS), __float_as_uint(m));
+        }
     }
 }
 

@@ -139,6 +139,7 @@ struct ProfRec { int cls; hipEvent_t a, b; };
 #endif
 constexpr float kGuardFc1Limit = 131072.0f;      // 2^17: half of the f16 saturation point of the fused kernel's hidden pre-activation
 constexpr int kGuardSlots = 4;                   // read-backs of the range guard in flight (one per encode call)
+constexpr int kAmaxSlots = 64;                   // = FVHD_AMAX_SLOTS of csrc/fvhd_common.h: words per step the kernels spread their atomics over
 struct GuardSlot { unsigned* host = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
 struct GuardHit { int step; float amax; };
 
@@ -496,11 +497,12 @@ void guard_free(fvhd_ctx* c)
 int guard_alloc(fvhd_ctx* c, int n)
 {
     guard_free(c);
-    hipError_t e = hipMalloc((void**)&c->guard_dev, (size_t)n * 4);
+    const size_t bytes = (size_t)n * kAmaxSlots * 4;
+    hipError_t e = hipMalloc((void**)&c->guard_dev, bytes);
     if (e != hipSuccess) return hip_fail("hipMalloc(range guard)", e);
-    e = hipMemset(c->guard_dev, 0, (size_t)n * 4);
+    e = hipMemset(c->guard_dev, 0, bytes);
     for (auto& sl : c->guard_slots) {
-        if (e == hipSuccess) e = hipHostMalloc((void**)&sl.host, (size_t)n * 4, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&sl.host, bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
     }
     if (e != hipSuccess) { guard_free(c); return hip_fail("range guard allocation", e); }
@@ -515,8 +517,10 @@ bool guard_check_slot(fvhd_ctx* c, const GuardSlot& sl)
     for (int i = 0; i < c->guard_n; ++i) {
         FfnW* f = ffn_of_step(c, i);
         if (!f || !f->fused || f->precision != FVHD_FFN_HALF) continue;
+        unsigned bits = 0;                          // maximum of the step's row (bit patterns of non-negative floats: unsigned order)
+        for (int k = 0; k < kAmaxSlots; ++k) bits = sl.host[(size_t)i * kAmaxSlots + k] > bits ? sl.host[(size_t)i * kAmaxSlots + k] : bits;
         float a;
-        memcpy(&a, &sl.host[i], 4);
+        memcpy(&a, &bits, 4);
         if (!(a <= (c->guard_site == 1 ? f->guard_limit_y : f->guard_limit))) {   // also NaN / Inf (they sort above every finite value in the reduction)
             f->precision = FVHD_FFN_BF16;
             c->guard_hits.push_back(GuardHit{i, a});
@@ -583,7 +587,7 @@ int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, in
     int e;
     const bool take_fused = f.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows);
     // range guard: the depthwise conv that feeds a half-precision fused block also reduces max |A| into this step's slot
-    unsigned* amax = (c->guard_active && c->guard_site == 0 && take_fused && f.precision == FVHD_FFN_HALF && step < c->guard_n) ? c->guard_dev + step : nullptr;
+    unsigned* amax = (c->guard_active && c->guard_site == 0 && take_fused && f.precision == FVHD_FFN_HALF && step < c->guard_n) ? c->guard_dev + (size_t)step * kAmaxSlots : nullptr;
     if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0, amax))) return e;
     if (c->audit_dev) {          // range audit: fc1 + bias as a plain GEMM into the hidden buffer, max |.| of it into this step's slot
         if ((e = run_gemm(c, st, C_FC1, c->wdev, f.fc1, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_BIAS))) return e;
@@ -647,7 +651,7 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
         const int step = (int)(&sp - c->m.steps.data());
         // range guard, site 1: the RepMixer's own output y is what the block's dw7x7 reads - max |y| into this step's slot
         const bool fused_half = blk.ffn.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows) && blk.ffn.precision == FVHD_FFN_HALF;
-        unsigned* amax = (c->guard_active && c->guard_site == 1 && fused_half && step < c->guard_n) ? c->guard_dev + step : nullptr;
+        unsigned* amax = (c->guard_active && c->guard_site == 1 && fused_half && step < c->guard_n) ? c->guard_dev + (size_t)step * kAmaxSlots : nullptr;
         if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0, amax))) return e;
         std::swap(X, T);
         return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, step);
@@ -770,7 +774,7 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
     c->guard_active = c->guard_on && c->guard_dev && c->guard_n == (int)c->m.steps.size() && !capturing && !c->audit_dev;
     if (c->guard_active) {
         guard_process(c, false);
-        const hipError_t he = hipMemsetAsync(c->guard_dev, 0, (size_t)c->guard_n * 4, st);
+        const hipError_t he = hipMemsetAsync(c->guard_dev, 0, (size_t)c->guard_n * kAmaxSlots * 4, st);
         if (he != hipSuccess) { c->guard_active = false; return hip_fail("hipMemsetAsync(range guard)", he); }
     }
     e = encode_body(c, images, img_dtype, B, out, out_dtype, st);
@@ -781,7 +785,7 @@ int encode_impl(fvhd_ctx* c, const void* images, int img_dtype, int B, void* out
             sl.pending = false;
             if (guard_check_slot(c, sl)) { (void)hipDeviceSynchronize(); clear_graphs(c); }
         }
-        hipError_t he = hipMemcpyAsync(sl.host, c->guard_dev, (size_t)c->guard_n * 4, hipMemcpyDeviceToHost, st);
+        hipError_t he = hipMemcpyAsync(sl.host, c->guard_dev, (size_t)c->guard_n * kAmaxSlots * 4, hipMemcpyDeviceToHost, st);
         if (he == hipSuccess) he = hipEventRecord(sl.ev, st);
         if (he == hipSuccess) { sl.pending = true; c->guard_next = (c->guard_next + 1) % kGuardSlots; }
         else (void)hipGetLastError();            // the guard is best effort: a failed read-back never fails the encode
@@ -1249,8 +1253,8 @@ int fvhd_op_dwconv(fvhd_stream_t st, const void* x, void* y, const float* w, con
     return e ? hip_fail("fvhd_op_dwconv", (hipError_t)e) : 0;
 }
 
-// The ConvFFN's depthwise 7x7 (stride 1, folded BatchNorm bias) with the range guard's reduction: amax_bits (device, 4 bytes, zeroed by the
-// caller) receives max |y| as the fp32 bit pattern of a non-negative number.  mfma != 0: the matrix-core kernel (its shape rules), 0: the VALU kernel
+// The ConvFFN's depthwise 7x7 (stride 1, folded BatchNorm bias) with the range guard's reduction: amax_bits (device, FVHD_AMAX_SLOTS = 64
+// words, zeroed by the caller) receives max |y| as fp32 bit patterns of non-negative numbers - the maximum over the 64 words is the result.  mfma != 0: the matrix-core kernel (its shape rules), 0: the VALU kernel
 int fvhd_op_dw7_amax(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, int mfma, void* amax_bits)
 {
     if (!x || !y || !w || !amax_bits) return fail("fvhd_op_dw7_amax: NULL pointer");

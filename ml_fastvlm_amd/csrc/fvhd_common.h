@@ -85,6 +85,12 @@ FVHD_DEV int xcd_remap(int b, int nwg) {
     return base + idx;
 }
 
+// ---- range-guard maxima (round 5) ------------------------------------------------------------------------------------
+// A kernel that reduces max |.| for the range guard publishes it with ONE atomicMax per workgroup into slot blockIdx.x % FVHD_AMAX_SLOTS of a
+// row of FVHD_AMAX_SLOTS words (fp32 bit patterns of non-negative numbers); the reader takes the maximum of the row.  One word for the whole
+// launch (first version) serialised 1536-6144 atomics on one address as the workgroups of a launch finish together: +10 us on a 52-us launch.
+#define FVHD_AMAX_SLOTS 64
+
 // ---- wave64 reductions ----------------------------------------------------------------------------
 FVHD_DEV float wave_sum(float v) {
 #pragma unroll

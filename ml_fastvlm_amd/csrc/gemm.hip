@@ -56,19 +56,25 @@ FVHD_DEV int lds_off(int row, int ks)
 // (EpiGrp, wrow_of_lds_row, wpiece_row, wpiece_lane_row, epi_col: gemm_layout.h - shared with the CPU test of the mapping)
 // ---- epilogue of one wave's (16 MF) x (16 NF) block.  GRP = 1: lane holds out[m][n .. n+3], m = mw + 16 i + lr, n = nw + 16 j + 4 g;
 // GRP = 2 / 4: out[m][n .. n + 4 GRP - 1], n = nw + 16 GRP jb + 4 GRP g, as acc[i][GRP jb .. GRP jb + GRP - 1]
-// ROWMAJOR (the streaming kernels, whose occupancy the LDS ring fixes at one workgroup per CU): rows outermost, see below; the register-
-// prefetch kernel v1 keeps the column groups outermost - the preloaded bias / layer-scale vectors of the row-major walk would take its
-// GELU / residual variants from 168 to 174-178 registers, i.e. from three resident workgroups to two
+// ROWMAJOR (requested by the streaming kernels, whose occupancy the LDS ring fixes at one workgroup per CU; honoured for EPI_NONE only):
+// rows outermost, see below.  Measured on one box (profiles/r05_gemm_epilogue_walk_ab.log, B = 32): the row-major walk brings WRITE_SIZE
+// to 1.00-1.06x the algorithmic bytes for every class, costs the plain epilogue (qkv) nothing - and the epilogues that carry bias / GELU /
+// layer-scale vectors 8-33 % of a launch (fc1 0.96 -> 1.09 ms per step, proj 0.356 -> 0.41, 1x1 0.35 -> 0.38, projector 0.081 -> 0.108;
+// whole step 23.93 -> 24.20 ms).  The write amplification of the column-major walk (1.18-1.31x) is not a time cost: those keep it.  The
+// register-prefetch kernel v1 keeps it too - the preloaded vectors of the row-major walk would take its GELU / residual variants from 168
+// to 174-178 registers, i.e. from three resident workgroups to two.
 // (-DFVHD_GEMM_EPI_COLMAJOR: the column-group-outermost walk everywhere, for same-box A/B runs: FVHD_VARIANT_TAG=cm)
 template <int MF, int NF, int EPI, int ODT, bool ROWMAJOR_ = false>
 FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias, const float* __restrict__ ls, const bf16* resid, void* out,
                             int M, int N, int mw, int nw, int lr, int g)
 {
     constexpr int GRP = EpiGrp<NF, EPI, ODT>::value;
-#ifdef FVHD_GEMM_EPI_COLMAJOR
+#if defined(FVHD_GEMM_EPI_COLMAJOR)
     constexpr bool ROWMAJOR = false;
-#else
+#elif defined(FVHD_GEMM_EPI_ROWMAJOR)           // the row-major walk for every epilogue of the streaming kernels (A/B: FVHD_VARIANT_TAG=rm)
     constexpr bool ROWMAJOR = ROWMAJOR_;
+#else
+    constexpr bool ROWMAJOR = ROWMAJOR_ && EPI == EPI_NONE;
 #endif
     if constexpr (GRP == 1) {
 #pragma unroll

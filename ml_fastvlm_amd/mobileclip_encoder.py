@@ -128,11 +128,12 @@ class MobileCLIPVisionTower(nn.Module):
         # the range guard (include/fvhd.h "range guard"): always on unless "off"; "strict" = poll synchronously after every call and
         # re-encode the batch when a block crossed its limit (the result of every call is then inside the proven range, at the price of
         # one host synchronisation per call); "on" (default) = asynchronous: the block is moved before the NEXT call, with a warning
+        # (unset / None = tri-state like the other options: the library's own setting - on unless FVHD_RANGE_GUARD=0 - is left alone)
         guard = getattr(args, "mm_vision_range_guard", None)
-        guard = "on" if guard in (None, True) else "off" if guard is False else guard
-        if guard not in ("on", "off", "strict"):
+        guard = "on" if guard is True else "off" if guard is False else guard
+        if guard not in (None, "on", "off", "strict"):
             raise ValueError(f"mm_vision_range_guard must be 'on', 'off' or 'strict', got {guard!r}")
-        self.range_guard = guard
+        self._range_guard = guard
         # expected batch size (sizes the library's workspace up front; it grows geometrically when a larger batch arrives)
         self._batch_hint = max(1, int(getattr(args, "mm_vision_max_batch", 1) or 1))
         self._ctx: Optional[_lib.Context] = None
@@ -178,6 +179,14 @@ class MobileCLIPVisionTower(nn.Module):
         self._ffn_audits_left = self.ffn_audit_batches
 
     @property
+    def range_guard(self) -> str:
+        """"on" (default), "strict" or "off"; unset = "on" unless the library was created with FVHD_RANGE_GUARD=0 in the environment"""
+        if self._range_guard is not None:
+            return self._range_guard
+        import os
+        return "off" if os.environ.get("FVHD_RANGE_GUARD", "1") == "0" else "on"
+
+    @property
     def _ffn_audited(self) -> bool:
         """"auto": has the current weight set seen all of its calibration batches?"""
         return self._ffn_audits_left <= 0
@@ -208,7 +217,8 @@ class MobileCLIPVisionTower(nn.Module):
             self._ctx.finalize()
             self._dirty = False
             self._apply_ffn_precision(self._ctx)
-        self._ctx.set_range_guard(self.range_guard != "off")
+        if self._range_guard is not None:
+            self._ctx.set_range_guard(self._range_guard != "off")
         if self.attention_fp8 is not None:
             self._ctx.set_attention_fp8(self.attention_fp8)
         if self.hip_graph is not None:

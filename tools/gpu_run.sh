@@ -179,6 +179,21 @@ PY
         echo "--- $mode"; cat ${O}_bygrid_${mode}.md | cut -c1-170
     done
     ;;
+r5d)        # round 5, fourth call: amax through 64 slots + one atomic per workgroup: tests, guard on / off on one box
+    timeout 600 python -m pytest tests/test_gpu_ffn_precision.py tests/test_gpu_ops.py -k "not attention and not ffn_fused and not stem" -m gpu -q --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -6 ${O}_pytest.log | cut -c1-300
+    run_bench() { # label, env...
+        local label=$1; shift
+        env "$@" timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_${label}.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_${label}.json")); print("${label}", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("gemm") or k in ("projector", "dw7", "dw3", "ffn_fused")})
+PY
+    }
+    run_bench guard_on FVHD_RANGE_GUARD=1
+    run_bench guard_off FVHD_RANGE_GUARD=0
+    run_bench guard_on2 FVHD_RANGE_GUARD=1
+    run_bench guard_off2 FVHD_RANGE_GUARD=0
+    run_bench guard_dw3 FVHD_GUARD_SITE=1
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;
