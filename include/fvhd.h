@@ -134,9 +134,9 @@ int fvhd_audit_ranges(fvhd_ctx* ctx, const void* images, int img_dtype, int batc
  * polled): graph-capturing callers calibrate with fvhd_audit_ranges first.
  * WHERE the maximum is taken (FVHD_GUARD_SITE in the environment of fvhd_create; default 0): 0 = max |A| inside the dw7x7 (+BN) kernel, limit as
  * above; 1 = one convolution earlier, max |y| of the RepMixer output inside the dw3x3 kernel, with |A_c| <= L1(folded 7x7 taps of c) max|y| +
- * |folded BN bias_c|, i.e. limit_y = (limit - max_c |bias_c|) / max_c L1(taps_c) - a looser bound (by the 7x7 taps' L1 norm, 2-5x).  Measured
- * on one box, whole step at B = 32 (profiles/r05_guard_site_persist_ab.log): site 0 24.26 ms, site 1 24.53, guard off 24.52 / 24.51 - the reduction costs
- * the matrix-core dw7x7 class 5 % (3.54 -> 3.72 ms) and the step nothing.
+ * |folded BN bias_c|, i.e. limit_y = (limit - max_c |bias_c|) / max_c L1(taps_c) - a looser bound (by the 7x7 taps' L1 norm, 2-7x: it moves
+ * blocks to the slower form sooner than needed).  Measured on one box, whole step at B = 32 (profiles/r05_guard_cost_ab.log): guard on
+ * (site 0) 23.76 / 23.77 ms, off 23.71 / 23.69 = 0.27 %; site 1 23.62 (one run).
  *   fvhd_set_range_guard(ctx, 0 / 1)   - default 1 (environment: FVHD_RANGE_GUARD=0).
  *   fvhd_range_guard_limit             - the limit on the tracked maximum (max|A| / max|y|) of a fused step (INFINITY if the weights are all
  *                                        zero, < 0 if the block can never run the half form).

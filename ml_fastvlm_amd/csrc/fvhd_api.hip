@@ -135,7 +135,7 @@ struct Model {
 
 struct ProfRec { int cls; hipEvent_t a, b; };
 #ifndef FVHD_GUARD_SITE_DEFAULT
-#define FVHD_GUARD_SITE_DEFAULT 0      // measured (profiles/r05_guard_site_persist_ab.log, five runs on one box): site 0 24.26 ms per step, site 1 24.53, guard off 24.52
+#define FVHD_GUARD_SITE_DEFAULT 0      // the tighter bound; both sites cost < 0.3 % of the step since the slot fix (profiles/r05_guard_cost_ab.log)
 #endif
 constexpr float kGuardFc1Limit = 131072.0f;      // 2^17: half of the f16 saturation point of the fused kernel's hidden pre-activation
 constexpr int kGuardSlots = 4;                   // read-backs of the range guard in flight (one per encode call)

@@ -339,10 +339,8 @@ class MobileCLIPVisionTower(nn.Module):
     def _after_encode(self, ctx, rerun=None):
         """range guard: report (and remember across re-packs) the blocks the library moved to the bf16-operand form.  "strict": wait for this
         call's read-back and run the batch again if it crossed a limit."""
-        if self.range_guard == "off":
-            return
-        if self.range_guard == "strict" and torch.cuda.is_current_stream_capturing():
-            return
+        if self.range_guard == "off" or torch.cuda.is_current_stream_capturing():
+            return                              # (a capturing caller: the library's guard is inactive, and polling events is not capture-safe)
         hits = ctx.range_guard_poll(wait=self.range_guard == "strict")
         if not hits:
             return

@@ -194,6 +194,10 @@ PY
     run_bench guard_off2 FVHD_RANGE_GUARD=0
     run_bench guard_dw3 FVHD_GUARD_SITE=1
     ;;
+r5final)    # round 5: the whole GPU suite on the final binary, then its evidence (bench line, small batches, power, PMC passes, TTFT trace)
+    timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --durations=8 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -14 ${O}_pytest.log | cut -c1-300
+    bash tools/gpu_run.sh final ${TAG}
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;
