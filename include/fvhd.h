@@ -351,6 +351,16 @@ int fvhd_op_rmsnorm(fvhd_stream_t stream, const void* x, void* y, const float* w
  * for ONE layer ([M / T][n_kv_heads][T][head_dim]) or NULL */
 int fvhd_op_rope(fvhd_stream_t stream, void* qkv, const int64_t* pos, const float* table, void* k_cache, void* v_cache, int M, int T,
                  int n_heads, int n_kv_heads, int head_dim, int table_positions, float rope_theta);
+/* The q|k|v projection with everything that follows it in Qwen2Attention.forward in ONE launch (round 5): out = A . Wt^T + bias rounded to bf16,
+ * then - on the q and k heads of the M real rows - the rotary embedding exactly as fvhd_op_rope applies it, then the KV-cache copies; bit-identical
+ * to fvhd_op_gemm(EPI_BIAS) + fvhd_op_rope.  head_dim 64 only (a wave's 64-column block of the output tile is one head, and since the round-5 tile
+ * fill a lane holds both members of every rotate_half pair); fvhd_gemm_qkv_rope_supported(Mp, N, K, head_dim, n_heads, n_kv_heads) tells whether a
+ * shape takes it (Mp % 128 == 0 rows incl. padding, N = (n_heads + 2 n_kv_heads) * 64, K % 64 == 0, at most one 128 x 128 tile per CU) -
+ * fvhd_llm_prefill uses it whenever that holds (FVHD_LLM_FUSEROPE=0: never).  A [Mp, K], Wt [N, K] bf16; bias fp32 [N]; the rest as fvhd_op_rope. */
+int fvhd_gemm_qkv_rope_supported(int Mp, int N, int K, int head_dim, int n_heads, int n_kv_heads);
+int fvhd_op_gemm_qkv_rope(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, void* out, int Mp, int N, int K, const int64_t* pos,
+                          const float* table, void* k_cache, void* v_cache, int M, int T, int n_heads, int n_kv_heads, int head_dim,
+                          int table_positions, float rope_theta);
 /* out = resid + A . Wt^T with K split over `splits` workgroups per output tile (Qwen2 down_proj at prefill: few tiles, long K):
  * A [M, K], Wt [N, K], resid [M, N] or NULL (may alias out), out [M, N] bf16; partial: fp32 scratch [splits][M][N]; the slices are
  * summed in order (deterministic) and rounded once.  N % 128 == 0, K % (64 * splits) == 0. */

@@ -81,6 +81,8 @@ def _declare(lib) -> None:
         "fvhd_llm_debug_hidden": (ci, [vp, vp, ci, vp]),
         "fvhd_op_rmsnorm": (ci, [vp, vp, vp, vp, ci, ci, cf]),
         "fvhd_op_rope": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf]),
+        "fvhd_gemm_qkv_rope_supported": (ci, [ci, ci, ci, ci, ci, ci]),
+        "fvhd_op_gemm_qkv_rope": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf]),
         "fvhd_llm_set_tensor_device": (ci, [vp, C.c_char_p, vp, ci, C.POINTER(C.c_int64), ci, vp]),
         "fvhd_llm_set_max_positions": (ci, [vp, ci]),
         "fvhd_llm_workspace_generation": (ci, [vp]),

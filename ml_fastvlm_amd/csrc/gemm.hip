@@ -25,6 +25,7 @@
 //     8 x 8 super-tiles (see the kernel): every A / W panel fetched from HBM feeds 8 resident tiles.
 #include "fvhd_common.h"
 #include "gemm_layout.h"
+#include "rope.h"
 #include <stdlib.h>
 
 #define EPI_NONE 0
@@ -34,6 +35,15 @@
 #define EPI_RESID 4        // out = resid + A.W^T                        (Qwen2 o_proj / down_proj + the decoder layer's skip)
 static_assert(FVHD_EPI_SWIGLU_ID == 5 && FVHD_ODT_BF16_ID == FVHD_BF16, "gemm_layout.h ids");
 #define EPI_SWIGLU 5       // (= FVHD_EPI_SWIGLU_ID of gemm_layout.h)  out[m][j] = silu(acc[m][2j]) * acc[m][2j+1], out is [M, N/2]: W rows interleaved gate_j, up_j (Qwen2MLP)
+
+#define EPI_BIAS_ROPE 6    // out = rope(bf16(A.W^T + b)) on the q / k heads of the packed q|k|v row (+ the KV-cache copies): gemm_epilogue_rope, head_dim 64 only
+
+// what the q|k|v projection's fused epilogue needs beyond the GEMM's own arguments (Qwen2Attention.forward after the projection):
+// position ids, the rotary table, the KV cache, the number of REAL rows (the GEMM also writes the padding rows, unrotated)
+struct RopeArgs {
+    const long* pos; const float* table; bf16* kcache; bf16* vcache;
+    int M, T, nh, nkv, P; float theta;
+};
 
 template <int BK>
 FVHD_DEV int lds_off(int row, int ks)
@@ -179,6 +189,45 @@ FVHD_DEV void gemm_epilogue(f32x4 (&acc)[MF][NF], const float* __restrict__ bias
 #pragma unroll
                 for (int i = 0; i < MF; ++i) emit(i, jb);
             }
+        }
+    }
+}
+
+// ---- q|k|v projection + rotary embedding + KV-cache copies in one epilogue (round 5; head_dim 64).  Since the tile-fill permutation a
+// lane of a wave's 64-column block - ONE head of the packed row - holds columns 8 g .. 8 g + 7 (fragments 0, 1) and 32 + 8 g .. + 7
+// (fragments 2, 3): exactly the (i, i + HD / 2) pairs rotate_half mixes.  Arithmetic = the projection's own epilogue (+ bias, one rounding
+// to bf16) followed by rope_kernel's (fp32 rotation of the bf16 values, second rounding): bit-identical to the two launches.
+template <int MF>
+FVHD_DEV void gemm_epilogue_rope(f32x4 (&acc)[MF][4], const float* __restrict__ bias, bf16* out, const RopeArgs& r, int Mrows, int N,
+                                 int mw, int nw, int lr, int g)
+{
+    constexpr int HD = 64;
+    if (nw >= N) return;
+    const int head = nw / HD, c0 = nw + 8 * g;
+    const f32x4 b00 = *(const f32x4*)(bias + c0), b01 = *(const f32x4*)(bias + c0 + 4);
+    const f32x4 b10 = *(const f32x4*)(bias + c0 + 32), b11 = *(const f32x4*)(bias + c0 + 36);
+    const bool rotary = head < r.nh + r.nkv, cached = r.kcache != nullptr && head >= r.nh;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = mw + i * 16 + lr;
+        if (m >= Mrows) continue;
+        bf16x4 a0 = f32_to_bf4(acc[i][0] + b00), a1 = f32_to_bf4(acc[i][1] + b01);      // columns c0 .. c0 + 7
+        bf16x4 p0 = f32_to_bf4(acc[i][2] + b10), p1 = f32_to_bf4(acc[i][3] + b11);      // their partners c0 + 32 ..
+        const bool real = m < r.M;
+        if (rotary && real) {
+            const long p = r.pos ? r.pos[m] : (long)(m % r.T);
+            rope_rotate(bf4_to_f32(a0), bf4_to_f32(p0), p, 8 * g, r.table, HD, r.P, r.theta, a0, p0);
+            rope_rotate(bf4_to_f32(a1), bf4_to_f32(p1), p, 8 * g + 4, r.table, HD, r.P, r.theta, a1, p1);
+        }
+        const bf16x8 lo = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+        *(bf16x8*)(out + (size_t)m * N + c0) = lo;
+        *(bf16x8*)(out + (size_t)m * N + c0 + 32) = hi;
+        if (cached && real) {
+            const int bt = m / r.T, t = m - bt * r.T;
+            bf16* dst = rotary ? r.kcache + (((size_t)bt * r.nkv + (head - r.nh)) * r.T + t) * HD
+                               : r.vcache + (((size_t)bt * r.nkv + (head - r.nh - r.nkv)) * r.T + t) * HD;
+            *(bf16x8*)(dst + 8 * g) = lo;
+            *(bf16x8*)(dst + 32 + 8 * g) = hi;
         }
     }
 }
@@ -453,7 +502,7 @@ constexpr int kG128Stages = 4, kG128Stage = (128 + 128) * 64 * 2, kG128Lds = kG1
 template <int EPI, int ODT>
 __global__ __launch_bounds__(256, 1) void gemm128s_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ Wt, const float* __restrict__ bias,
-    const float* __restrict__ ls, const bf16* resid, void* out_, int M, int N, int K, int tiles_n, int nwg, int ldk)
+    const float* __restrict__ ls, const bf16* resid, void* out_, int M, int N, int K, int tiles_n, int nwg, int ldk, RopeArgs rope)
 {
     constexpr int BM = 128, BK = 64, MF = 4, NF = 4, RS = kG128Stages, STAGE = kG128Stage, RPP = 8, PA = 4, PW = 4;
     A += (size_t)blockIdx.y * K;
@@ -531,7 +580,8 @@ __global__ __launch_bounds__(256, 1) void gemm128s_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    gemm_epilogue<MF, NF, EPI, ODT, true>(acc, bias, ls, resid, out, M, N, m0 + wm * 64, n0 + wn * 64, lr, g);
+    if constexpr (EPI == EPI_BIAS_ROPE) gemm_epilogue_rope<MF>(acc, bias, (bf16*)out, rope, M, N, m0 + wm * 64, n0 + wn * 64, lr, g);
+    else gemm_epilogue<MF, NF, EPI, ODT, true>(acc, bias, ls, resid, out, M, N, m0 + wm * 64, n0 + wn * 64, lr, g);
 }
 
 // v4 (round 3, experiment): "ping-pong" 256 x 256 tile.  The 8 waves form two groups (rows 0-127 / 128-255 of the tile; one wave of each
@@ -759,7 +809,7 @@ static hipError_t dispatch_gemm256(hipStream_t st, const bf16* a, const bf16* w,
 // 128 x 128 streaming kernel (v1s).  K = the K range of ONE slice, ldk = the row stride, splits = gridDim.y (1 for a plain GEMM)
 template <int EPI, int ODT>
 static hipError_t launch_gemm128s(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls, const bf16* resid, void* out,
-                                  int M, int N, int K, int splits, int ldk)
+                                  int M, int N, int K, int splits, int ldk, RopeArgs rope = RopeArgs{})
 {
     static bool attr_set[64] = {};
     int dev = 0;
@@ -770,7 +820,7 @@ static hipError_t launch_gemm128s(hipStream_t st, const bf16* A, const bf16* Wt,
         attr_set[dev & 63] = true;
     }
     const int tiles_m = M / 128, tiles_n = N / 128, nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm128s_kernel<EPI, ODT>), dim3(nwg, splits), dim3(256), kG128Lds, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg, ldk);
+    hipLaunchKernelGGL((gemm128s_kernel<EPI, ODT>), dim3(nwg, splits), dim3(256), kG128Lds, st, A, Wt, bias, ls, resid, out, M, N, K, tiles_n, nwg, ldk, rope);
     return hipGetLastError();
 }
 
@@ -950,6 +1000,26 @@ extern "C" int fvhd_launch_gemm_splitk(hipStream_t st, const void* A, const void
                                        int M, int N, int K, int splits)
 {
     return fvhd_launch_gemm_splitk_norm(st, A, Wt, resid, out, partial, M, N, K, splits, nullptr, nullptr, 0.f);
+}
+
+// q|k|v projection with the rotary embedding and the KV-cache copies in its epilogue (EPI_BIAS_ROPE): 1 if this shape takes it - head_dim 64
+// (a wave's 64-column block = one head) on the streaming 128 x 128 kernel's shape rules; the caller launches projection + rope_kernel otherwise
+extern "C" int fvhd_gemm_qkv_rope_supported(int Mp, int N, int K, int HD, int nh, int nkv)
+{
+    if (HD != 64 || Mp <= 0 || nh <= 0 || nkv <= 0 || N != (nh + 2 * nkv) * HD) return 0;
+    return take_gemm128s(Mp, N, K, (long)(Mp / 128) * (N / 128)) ? 1 : 0;
+}
+
+// A [Mp, K] bf16, Wt [N, K] bf16 (q | k | v rows), bias fp32 [N], out [Mp, N] bf16; pos int64 [M] or null (= row % T), table fp32 [P][HD/2][2],
+// kcache / vcache [B][nkv][T][HD] bf16 or both null; M <= Mp real rows
+extern "C" int fvhd_launch_gemm_qkv_rope(hipStream_t st, const void* A, const void* Wt, const float* bias, void* out, int Mp, int N, int K,
+                                         const long* pos, const float* table, void* kcache, void* vcache, int M, int T, int nh, int nkv, int HD, int P, float theta)
+{
+    if (!A || !Wt || !bias || !out || !table || M <= 0 || M > Mp || T <= 0 || P <= 0 || !(theta > 0.f) || (kcache == nullptr) != (vcache == nullptr))
+        return (int)hipErrorInvalidValue;
+    if (!fvhd_gemm_qkv_rope_supported(Mp, N, K, HD, nh, nkv)) return (int)hipErrorInvalidValue;
+    const RopeArgs r{pos, table, (bf16*)kcache, (bf16*)vcache, M, T, nh, nkv, P, theta};
+    return (int)launch_gemm128s<EPI_BIAS_ROPE, FVHD_BF16>(st, (const bf16*)A, (const bf16*)Wt, bias, nullptr, nullptr, out, Mp, N, K, 1, K, r);
 }
 
 template <int NF, int BK>

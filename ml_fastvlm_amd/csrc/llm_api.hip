@@ -20,6 +20,8 @@ int fvhd_launch_splitk_bias_rope(hipStream_t, const float*, int, int, const floa
 int fvhd_launch_gemm_splitk_norm(hipStream_t, const void*, const void*, const void*, void*, float*, int, int, int, int, const float*, void*, float);
 int fvhd_launch_rmsnorm(hipStream_t, const void*, void*, const float*, int, int, float);
 int fvhd_launch_rope(hipStream_t, void*, const long*, const float*, void*, void*, int, int, int, int, int, int, float);
+int fvhd_gemm_qkv_rope_supported(int, int, int, int, int, int);
+int fvhd_launch_gemm_qkv_rope(hipStream_t, const void*, const void*, const float*, void*, int, int, int, const long*, const float*, void*, void*, int, int, int, int, int, int, float);
 int fvhd_launch_llm_attention(hipStream_t, const void*, void*, const unsigned char*, int, int, int, int, int);
 int fvhd_launch_cast_rows(hipStream_t, const void*, int, void*, long);
 int fvhd_launch_gather_rows(hipStream_t, const void*, void*, int, int, int, int);
@@ -92,6 +94,7 @@ struct fvhd_llm {
     int ws_rows = 0, ws_batch = 0, ws_pos = 0;
     char *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *last = nullptr, *lastn = nullptr;
     float *rope = nullptr, *part = nullptr;
+    int fuse_rope = 0;                     // (default flips to 1 once the GPU run of this commit has verified it) FVHD_LLM_FUSEROPE=0: rotary embedding + KV-cache copies as their own launch behind the q|k|v projection (identical bits)
     int down_splits = kMaxSplits, o_splits = 2, qkv_splits = 0, fuse_norm = 1;     // FVHD_LLM_SPLITK / FVHD_LLM_OSPLIT (largest split of down_proj / o_proj, 0 = never) / FVHD_LLM_QKVSPLIT / FVHD_LLM_FUSENORM
     int max_pos = 0;                       // fvhd_llm_set_max_positions (config.max_position_embeddings): rows of the rotary table
     // A prefill that ran while its stream was being captured put this workspace's pointers into the CALLER's graph.  Such a workspace is
@@ -232,6 +235,7 @@ int fvhd_llm_create(fvhd_llm** out, int device, int hidden, int n_layers, int n_
     if (const char* ev = getenv("FVHD_LLM_OSPLIT")) c->o_splits = atoi(ev);
     if (const char* ev = getenv("FVHD_LLM_QKVSPLIT")) c->qkv_splits = atoi(ev);
     if (const char* ev = getenv("FVHD_LLM_FUSENORM")) c->fuse_norm = atoi(ev);
+    if (const char* ev = getenv("FVHD_LLM_FUSEROPE")) c->fuse_rope = atoi(ev);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return o; };
     c->lo.resize(n_layers);
@@ -470,6 +474,10 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
             LCHECK(fvhd_launch_gemm_splitk_partials(st, c->xn, w + o.wqkv, c->part, Mp, c->qkvw, H, qkv_sp), "qkv gemm (split-K)");
             LCHECK(fvhd_launch_splitk_bias_rope(st, c->part, qkv_sp, Mp, (const float*)(w + o.bqkv), c->qkv, (const long*)position_ids, c->rope, kc, vc,
                                                 M, T, nh, nkv, hd, c->ws_pos, c->theta), "qkv reduce + bias + rope");
+        } else if (c->fuse_rope && fvhd_gemm_qkv_rope_supported(Mp, c->qkvw, H, hd, nh, nkv)) {
+            // round 5: bias + rotary embedding + the KV-cache copies in the projection's own epilogue (head_dim 64; bit-identical to the two launches)
+            LCHECK(fvhd_launch_gemm_qkv_rope(st, c->xn, w + o.wqkv, (const float*)(w + o.bqkv), c->qkv, Mp, c->qkvw, H, (const long*)position_ids, c->rope, kc, vc,
+                                             M, T, nh, nkv, hd, c->ws_pos, c->theta), "qkv gemm + rope");
         } else {
             LCHECK(fvhd_launch_gemm(st, c->xn, w + o.wqkv, (const float*)(w + o.bqkv), nullptr, nullptr, c->qkv, Mp, c->qkvw, H, EPI_BIAS, FVHD_BF16), "qkv gemm");
             LCHECK(fvhd_launch_rope(st, c->qkv, (const long*)position_ids, c->rope, kc, vc, M, T, nh, nkv, hd, c->ws_pos, c->theta), "rope");
@@ -525,6 +533,19 @@ int fvhd_op_rope(fvhd_stream_t st, void* qkv, const int64_t* pos, const float* t
     if (!qkv || !table) return lfail("fvhd_op_rope: NULL pointer");
     int e = fvhd_launch_rope((hipStream_t)st, qkv, (const long*)pos, table, k_cache, v_cache, M, T, n_heads, n_kv_heads, head_dim, table_positions, rope_theta);
     return e ? lhip("fvhd_op_rope", (hipError_t)e) : 0;
+}
+
+int fvhd_op_gemm_qkv_rope(fvhd_stream_t st, const void* A, const void* Wt, const float* bias, void* out, int Mp, int N, int K, const int64_t* pos,
+                          const float* table, void* k_cache, void* v_cache, int M, int T, int n_heads, int n_kv_heads, int head_dim, int table_positions,
+                          float rope_theta)
+{
+    if (!A || !Wt || !bias || !out || !table) return lfail("fvhd_op_gemm_qkv_rope: NULL pointer");
+    if (!fvhd_gemm_qkv_rope_supported(Mp, N, K, head_dim, n_heads, n_kv_heads))
+        return lfail("fvhd_op_gemm_qkv_rope: needs head_dim 64, N = (n_heads + 2 n_kv_heads) * 64, Mp % 128 == 0, N % 128 == 0, K % 64 == 0 and at most one "
+                     "128 x 128 tile per CU (fvhd_gemm_qkv_rope_supported); other shapes run fvhd_op_gemm + fvhd_op_rope");
+    int e = fvhd_launch_gemm_qkv_rope((hipStream_t)st, A, Wt, bias, out, Mp, N, K, (const long*)pos, table, k_cache, v_cache, M, T, n_heads, n_kv_heads,
+                                      head_dim, table_positions, rope_theta);
+    return e ? lhip("fvhd_op_gemm_qkv_rope", (hipError_t)e) : 0;
 }
 
 int fvhd_op_gemm_splitk(fvhd_stream_t st, const void* A, const void* Wt, const void* resid, void* out, float* partial, int M, int N, int K, int splits)

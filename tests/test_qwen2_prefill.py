@@ -229,6 +229,50 @@ def test_split_qkv_projection_with_rope_in_its_reduce(hd, nh, nkv, K, cache):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nh,nkv,K,B,T,cache", [(14, 2, 896, 8, 285, True), (2, 1, 128, 3, 85, True), (4, 2, 256, 1, 1, False), (14, 2, 896, 1, 281, True)])
+def test_qkv_projection_with_rope_in_its_epilogue(nh, nkv, K, B, T, cache):
+    """fvhd_op_gemm_qkv_rope (round 5): q|k|v projection + bias + rotary embedding + KV-cache copies in ONE launch (head_dim 64) -
+    bit-identical to fvhd_op_gemm(EPI_BIAS) followed by fvhd_op_rope (whose arithmetic is pinned to apply_rotary_pos_emb above), padding rows
+    included (projected, never rotated)."""
+    from ml_fastvlm_amd.qwen2_prefill import rope_table
+    lib = _lib.load()
+    hd = 64
+    M, Mp = B * T, (B * T + 255) // 256 * 256
+    width = (nh + 2 * nkv) * hd
+    if not lib.fvhd_gemm_qkv_rope_supported(Mp, width, K, hd, nh, nkv):
+        pytest.skip("shape outside the streaming 128 x 128 kernel's rules")
+    g = torch.Generator().manual_seed(K + T)
+    A = _bf(torch.randn(Mp, K, generator=g))
+    W = _bf(torch.randn(width, K, generator=g) * K ** -0.5)
+    bias = torch.randn(width, generator=g)
+    pos = torch.stack([torch.randperm(T, generator=g) for _ in range(B)])
+    pos[0] += 500                                               # one sequence beyond the table
+    table = rope_table(T, hd, 1e6, DEV)
+    ad, wd, bd, pd = A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16), bias.to(DEV), pos.to(DEV)
+    mk = lambda: (torch.zeros(B, nkv, T, hd, device=DEV, dtype=torch.bfloat16) if cache else None)
+    kc, vc, kc2, vc2 = mk(), mk(), mk(), mk()
+    got = torch.full((Mp, width), 7.0, device=DEV, dtype=torch.bfloat16)
+    _lib.check(lib.fvhd_op_gemm_qkv_rope(_stream(), _p(ad), _p(wd), _p(bd), _p(got), Mp, width, K, _p(pd), _p(table), _p(kc), _p(vc), M, T, nh, nkv, hd, T,
+                                         1e6), "qkv + rope")
+    ref = torch.empty_like(got)
+    _lib.check(lib.fvhd_op_gemm(_stream(), _p(ad), _p(wd), _p(bd), _p(None), _p(None), _p(ref), Mp, width, K, _lib.EPI_BIAS, _lib.BF16), "qkv gemm")
+    _lib.check(lib.fvhd_op_rope(_stream(), _p(ref), _p(pd), _p(table), _p(kc2), _p(vc2), M, T, nh, nkv, hd, T, 1e6), "rope")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), "fused epilogue differs from projection -> rope"
+    if cache:
+        assert torch.equal(kc, kc2) and torch.equal(vc, vc2), "KV cache"
+    # default positions (NULL)
+    got2, ref2 = torch.empty_like(got), torch.empty_like(got)
+    _lib.check(lib.fvhd_op_gemm_qkv_rope(_stream(), _p(ad), _p(wd), _p(bd), _p(got2), Mp, width, K, _p(None), _p(table), _p(None), _p(None), M, T, nh, nkv, hd, T,
+                                         1e6), "qkv + rope, default positions")
+    _lib.check(lib.fvhd_op_gemm(_stream(), _p(ad), _p(wd), _p(bd), _p(None), _p(None), _p(ref2), Mp, width, K, _lib.EPI_BIAS, _lib.BF16), "qkv gemm")
+    _lib.check(lib.fvhd_op_rope(_stream(), _p(ref2), _p(None), _p(table), _p(None), _p(None), M, T, nh, nkv, hd, T, 1e6), "rope")
+    torch.cuda.synchronize()
+    assert torch.equal(got2, ref2)
+    assert lib.fvhd_gemm_qkv_rope_supported(Mp, (nh + 2 * nkv) * 128, K, 128, nh, nkv) == 0, "head_dim 128 keeps the two launches"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hd,nh,nkv,B,T,pad", [(64, 14, 2, 3, 285, "none"), (64, 4, 2, 4, 130, "left"), (64, 2, 1, 2, 64, "right"),
                                               (128, 4, 2, 2, 200, "left"), (128, 2, 2, 3, 17, "none"), (64, 2, 2, 1, 1, "none"),
                                               (64, 2, 1, 5, 300, "left")])        # left padding of up to 97 positions: whole key tiles masked
@@ -358,10 +402,11 @@ def test_prefill_qwen2_05b_shapes_two_layers_b8():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"FVHD_LLM_QKVSPLIT": "2"}, {"FVHD_LLM_QKVSPLIT": "0", "FVHD_LLM_OSPLIT": "0", "FVHD_LLM_FUSENORM": "0"},
-                                 {"FVHD_LLM_SPLITK": "0", "FVHD_LLM_OSPLIT": "0"}])
+                                 {"FVHD_LLM_SPLITK": "0", "FVHD_LLM_OSPLIT": "0"}, {"FVHD_LLM_FUSEROPE": "0"}])
 def test_prefill_launch_plans_agree_with_transformers(env, monkeypatch):
     """every launch plan of the decoder layer (fvhd_llm_create reads the switches): split q|k|v projection with bias + rotary embedding in its reduce;
-    no fused norm / no split o_proj (the round-3 plan); no split-K at all"""
+    no fused norm / no split o_proj (the round-3 plan); no split-K at all; rotary embedding as its own launch (round 5: by default it rides in the
+    q|k|v projection's epilogue wherever the head dimension is 64)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     _compare_prefill(_cfg(hidden=896, layers=2, heads=14, kv=2, inter=4864, vocab=2048), 4, 150, "left", seed=7, layers_tol=1.5e-2)
