@@ -198,6 +198,23 @@ r5final)    # round 5: the whole GPU suite on the final binary, then its evidenc
     timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --durations=8 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -14 ${O}_pytest.log | cut -c1-300
     bash tools/gpu_run.sh final ${TAG}
     ;;
+r5e)        # round 5: rotary embedding in the q|k|v projection's epilogue - tests, TTFT A/B on one box, the prefill's kernel trace
+    FVHD_LLM_FUSEROPE=1 timeout 600 python -m pytest tests/test_qwen2_prefill.py tests/test_gpu_ttft.py -m gpu -q --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -6 ${O}_pytest.log | cut -c1-300
+    for v in "unfused FVHD_LLM_FUSEROPE=0" "fused FVHD_LLM_FUSEROPE=1" "unfused2 FVHD_LLM_FUSEROPE=0" "fused2 FVHD_LLM_FUSEROPE=1"; do
+        set -- $v
+        env $2 timeout 300 python bench.py --ttft --steps 20 --warmup 3 > ${O}_ttft_$1.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_ttft_$1.json")); c=d["config"]; print("ttft $1", d["value"], c["encode_images_ms"], c["splice_ms"], c["prefill_first_token_ms"], c["prefill_roofline"]["frac"])
+PY
+    done
+    for v in "unfused FVHD_LLM_FUSEROPE=0" "fused FVHD_LLM_FUSEROPE=1"; do
+        set -- $v
+        env $2 timeout 300 python bench.py --ttft --batch 1 --steps 20 --warmup 3 > ${O}_ttft_b1_$1.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_ttft_b1_$1.json")); c=d["config"]; print("ttft B=1 $1", d["value"], c["encode_images_ms"], c["splice_ms"], c["prefill_first_token_ms"], c["prefill_roofline"]["frac"])
+PY
+    done
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;
