@@ -46,7 +46,7 @@ typedef void* fvhd_stream_t; /* hipStream_t */
  * (ml_fastvlm_amd/_lib.py does): the major part changes whenever an exported signature or the meaning of an argument changes.
  * 100 = rounds 1-3; round 4 changed signatures under the same number (fvhd_op_stem_fused + w2 / b2, fvhd_op_ffn_fused / fvhd_ffn_pack +
  * precision, fvhd_op_rope + rope_theta) - a mistake this number corrects; 500 = round 5 (adds the range guard, fvhd_op_dw7_amax,
- * fvhd_llm_* stream contract; no signature of 4xx changed). */
+ * fvhd_op_gemm_qkv_rope / fvhd_gemm_qkv_rope_supported, the fvhd_llm_* stream contract; no signature of round 4 changed). */
 #define FVHD_VERSION 500
 int fvhd_version(void);
 const char* fvhd_last_error(void);
@@ -356,7 +356,8 @@ int fvhd_op_rope(fvhd_stream_t stream, void* qkv, const int64_t* pos, const floa
  * to fvhd_op_gemm(EPI_BIAS) + fvhd_op_rope.  head_dim 64 only (a wave's 64-column block of the output tile is one head, and since the round-5 tile
  * fill a lane holds both members of every rotate_half pair); fvhd_gemm_qkv_rope_supported(Mp, N, K, head_dim, n_heads, n_kv_heads) tells whether a
  * shape takes it (Mp % 128 == 0 rows incl. padding, N = (n_heads + 2 n_kv_heads) * 64, K % 64 == 0, at most one 128 x 128 tile per CU) -
- * fvhd_llm_prefill uses it whenever that holds (FVHD_LLM_FUSEROPE=0: never).  A [Mp, K], Wt [N, K] bf16; bias fp32 [N]; the rest as fvhd_op_rope. */
+ * fvhd_llm_prefill uses it when FVHD_LLM_FUSEROPE=1 is set at fvhd_llm_create (measured neutral: the launch saved comes back as epilogue time -
+ * profiles/r05_ttft_fuserope_ab.log - so the default keeps the two launches).  A [Mp, K], Wt [N, K] bf16; bias fp32 [N]; the rest as fvhd_op_rope. */
 int fvhd_gemm_qkv_rope_supported(int Mp, int N, int K, int head_dim, int n_heads, int n_kv_heads);
 int fvhd_op_gemm_qkv_rope(fvhd_stream_t stream, const void* A, const void* Wt, const float* bias, void* out, int Mp, int N, int K, const int64_t* pos,
                           const float* table, void* k_cache, void* v_cache, int M, int T, int n_heads, int n_kv_heads, int head_dim,

@@ -94,7 +94,7 @@ struct fvhd_llm {
     int ws_rows = 0, ws_batch = 0, ws_pos = 0;
     char *h = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *act = nullptr, *last = nullptr, *lastn = nullptr;
     float *rope = nullptr, *part = nullptr;
-    int fuse_rope = 0;                     // (default flips to 1 once the GPU run of this commit has verified it) FVHD_LLM_FUSEROPE=0: rotary embedding + KV-cache copies as their own launch behind the q|k|v projection (identical bits)
+    int fuse_rope = 0;                     // FVHD_LLM_FUSEROPE=1: rotary embedding + KV-cache copies inside the q|k|v projection's epilogue instead of their own launch (identical bits; measured neutral - prefill 3.421 / 3.410 -> 3.404 / 3.407 ms at B = 8, 2.316 -> 2.342 at B = 1, profiles/r05_ttft_fuserope_ab.log: the 5.4-us launch saved comes back as epilogue time - so off by default)
     int down_splits = kMaxSplits, o_splits = 2, qkv_splits = 0, fuse_norm = 1;     // FVHD_LLM_SPLITK / FVHD_LLM_OSPLIT (largest split of down_proj / o_proj, 0 = never) / FVHD_LLM_QKVSPLIT / FVHD_LLM_FUSENORM
     int max_pos = 0;                       // fvhd_llm_set_max_positions (config.max_position_embeddings): rows of the rotary table
     // A prefill that ran while its stream was being captured put this workspace's pointers into the CALLER's graph.  Such a workspace is

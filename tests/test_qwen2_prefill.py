@@ -402,11 +402,10 @@ def test_prefill_qwen2_05b_shapes_two_layers_b8():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"FVHD_LLM_QKVSPLIT": "2"}, {"FVHD_LLM_QKVSPLIT": "0", "FVHD_LLM_OSPLIT": "0", "FVHD_LLM_FUSENORM": "0"},
-                                 {"FVHD_LLM_SPLITK": "0", "FVHD_LLM_OSPLIT": "0"}, {"FVHD_LLM_FUSEROPE": "0"}])
+                                 {"FVHD_LLM_SPLITK": "0", "FVHD_LLM_OSPLIT": "0"}, {"FVHD_LLM_FUSEROPE": "1"}])
 def test_prefill_launch_plans_agree_with_transformers(env, monkeypatch):
     """every launch plan of the decoder layer (fvhd_llm_create reads the switches): split q|k|v projection with bias + rotary embedding in its reduce;
-    no fused norm / no split o_proj (the round-3 plan); no split-K at all; rotary embedding as its own launch (round 5: by default it rides in the
-    q|k|v projection's epilogue wherever the head dimension is 64)"""
+    no fused norm / no split o_proj (the round-3 plan); no split-K at all; rotary embedding + KV-cache copies inside the q|k|v projection's epilogue (round 5, head_dim 64; opt-in: measured neutral)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     _compare_prefill(_cfg(hidden=896, layers=2, heads=14, kv=2, inter=4864, vocab=2048), 4, 150, "left", seed=7, layers_tol=1.5e-2)
