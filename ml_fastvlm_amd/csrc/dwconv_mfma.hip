@@ -48,6 +48,15 @@ constexpr int DWM_P = 80;        // pitch (px) of one channel row of the transpo
 #define DWM_RS_ 4
 #endif
 constexpr int DWM_RS = DWM_RS_;  // raw-row ring depth
+// Round 5: channels 8..15 of a transposed image start DWM_TSKEW elements (64 B) later than 8 * P.  The transposing ds_write_b16 of a half-wave
+// writes pixel runs of 32 B for BOTH channel halves (lane & 1): 8 rows of P = 80 apart is 1280 B = 0 mod the 128-B bank window of an LDS write -
+// a 2-way conflict on every one of the 24 writes per wave-row, a third of this kernel's LDS cycles (SQ_LDS_BANK_CONFLICT 33 %, profiles/r04 / r05
+// PMC summaries).  With the skew the two runs sit 64 B apart in the window; the A-operand ds_read_b64 of a half-wave touches ONE channel half
+// (lanes 0-31 = channels 0-7), so its conflict-free pattern only shifts.  -DDWM_TSKEW_=0 restores the round-4 layout (A/B).
+#ifndef DWM_TSKEW_
+#define DWM_TSKEW_ 32
+#endif
+constexpr int DWM_TSKEW = DWM_TSKEW_;
 #ifndef DWM_ABL                  // timing-only ablations (wrong results; bit 0: no transposing writes, 1: no staging writes, 2: no per-row barrier,
                                  // 3: no MFMAs, 4: no output stores, 5: no LDS-DMA inside the row loop, 6: no LDS reads inside the row loop,
                                  // 7: ONE output staging buffer (racy) - with -DDWM_RS_=5 the deeper ring in the same LDS)
@@ -59,7 +68,7 @@ template <int NW> struct DwmCfg {
     static constexpr int CW = 16 * NW, PXB = CW * 2;          // channels / bytes per pixel of the workgroup's block
     static constexpr int OPX = PXB + 16;                      // output staging: one pixel + 16 B pad (the 4 pixels of one ds_write_b16 on 4 bank groups)
     static constexpr int HALO = 64 * PXB;                     // byte offset of the halo pixels inside a raw row
-    static constexpr int RAWB = 72 * PXB, OB = 64 * OPX, TB = 16 * DWM_P * 2;       // TB: one transposed image; two per wave
+    static constexpr int RAWB = 72 * PXB, OB = 64 * OPX, TB = (16 * DWM_P + DWM_TSKEW) * 2;       // TB: one transposed image (+ the skew gap between its channel halves); two per wave
     static constexpr int NOB = (DWM_ABL & 128) ? 1 : 2;
     static constexpr int LDS = DWM_RS * RAWB + NOB * OB + NW * 2 * TB;
 };
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     // the image's own maximum), as fp32 bit patterns of non-negative numbers in a row of FVHD_AMAX_SLOTS words (fvhd_common.h) - the range
     // guard of the half-precision fused ConvFFN
     using K = DwmCfg<NW>;
-    constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = DWM_RS, P = DWM_P, OPX = K::OPX, RAWB = K::RAWB, OB = K::OB, TBY = K::TB;
+    constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = DWM_RS, P = DWM_P, OPX = K::OPX, RAWB = K::RAWB, OB = K::OB, TBY = K::TB, TE = TBY / 2, SK = DWM_TSKEW;   // TE: u16 elements of one transposed image
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* raw = smem;                                       // [RS][64 interior px | 8 halo px][PXB]  (NW = 4: chunks permuted inside every 1-KiB piece)
@@ -163,13 +172,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     unsigned tdst[3];                          // u16 index inside one T buffer
 #pragma unroll
     for (int m = 0; m < 3; ++m)
-        tdst[m] = (unsigned)((8 * (lane & 1)) * P + ((okm[m] && !(m == 2 && lane >= 16)) ? 32 * m + (lane >> 1) : IWX + ((lane >> 1) & 7)));
+        tdst[m] = (unsigned)((8 * (lane & 1)) * P + SK * (lane & 1) + ((okm[m] && !(m == 2 && lane >= 16)) ? 32 * m + (lane >> 1) : IWX + ((lane >> 1) & 7)));
     auto tr_read = [&](u32x4 (&v)[3], int slot) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) v[m] = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
     };
     auto tr_write1 = [&](const u32x4 (&v)[3], int tb, int m, int e) {       // element e (channel 8 half + e) of chunk m
-        u16* d = T + tb * (16 * P) + tdst[m];
+        u16* d = T + tb * TE + tdst[m];
         const unsigned wv_ = e < 2 ? v[m].x : e < 4 ? v[m].y : e < 6 ? v[m].z : v[m].w;
         d[e * P] = (e & 1) ? (u16)(wv_ >> 16) : (u16)wv_;
     };
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     // so that a wave's LDS traffic and its MFMAs overlap inside the wave (with one workgroup per CU - the 96-channel case - nothing
     // else would), and the per-row memory instructions sit behind the first MFMA group instead of in front of a stall.
     const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3);
-    const u16* rd = T + blk * P + 4 * q;
+    const u16* rd = T + blk * P + SK * (blk >> 3) + 4 * q;
 #pragma unroll
     for (int i = 0; i < RS; ++i) dma(min(r_lo + i, r_hi - 1), (r_lo + i) % RS);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                 asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(ov[0]), "+v"(ov[1]));
             } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a[0][t] = *(const s16x4*)&rd[tb * (16 * P) + 16 * t];
+            for (int t = 0; t < NT; ++t) a[0][t] = *(const s16x4*)&rd[tb * TE + 16 * t];
             tr_read(tv, nslot);
             o_read(ov, ob ^ 1);
             }
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                     asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(a[s][t]), "v"(bop[ky][s]));
                 if (!(DWM_ABL & 64) && k == 2) {
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) a[1][tt] = *(const s16x4*)&rd[tb * (16 * P) + 16 * tt + 4];
+                    for (int tt = 0; tt < NT; ++tt) a[1][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 4];
                 }
                 if (!(DWM_ABL & 16) && k == 5) o_store(ov, r - 4);                 // staged in the previous iteration
                 if (!(DWM_ABL & 32) && k == 8) dma(min(r + RS, r_hi - 1), slot);   // row r's slot: every wave transposed it before this iteration's barrier
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                 if (!(DWM_ABL & 1) && k >= 18 && k < 26) tr_write1(tv, tb ^ 1, 1, k - 18);
                 if (!(DWM_ABL & 64) && k == 30) {
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) a[2][tt] = *(const s16x4*)&rd[tb * (16 * P) + 16 * tt + 8];
+                    for (int tt = 0; tt < NT; ++tt) a[2][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 8];
                 }
                 if (!(DWM_ABL & 1) && k >= 32 && k < 40) tr_write1(tv, tb ^ 1, 2, k - 32);
                 if (k == 62) {

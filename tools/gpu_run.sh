@@ -215,6 +215,28 @@ d=json.load(open("${O}_ttft_b1_$1.json")); c=d["config"]; print("ttft B=1 $1", d
 PY
     done
     ;;
+r5f)        # round 5: skewed channel halves of the dw7 kernel's transposed image - tests, same-box A/B against -DDWM_TSKEW_=0, LDS conflict counters
+    timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_steps.py -k "dw or steps" -m gpu -q --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log | cut -c1-300
+    run_bench() { # label, env...
+        local label=$1; shift
+        env "$@" timeout 300 python bench.py --no-cpu-baseline --no-ttft > ${O}_bench_${label}.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_${label}.json")); print("${label}", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k in ("dw7", "dw3", "ffn_fused", "stem", "dw_down")})
+PY
+    }
+    run_bench skew FVHD_LIB=ml_fastvlm_amd/libfvhd.so
+    run_bench noskew FVHD_LIB=ml_fastvlm_amd/libfvhd_ts0.so
+    run_bench skew2 FVHD_LIB=ml_fastvlm_amd/libfvhd.so
+    run_bench noskew2 FVHD_LIB=ml_fastvlm_amd/libfvhd_ts0.so
+    CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-ttft"
+    for pass in trace grbm; do
+        extra=""; [ "$pass" = grbm ] && extra="--pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+        timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_${pass} -o ${pass} $extra -- $CMD > gpurun_out/${TAG}_${pass}.log 2>&1
+    done
+    python tools/pmc_summary.py ${TAG}_l gpurun_out/${TAG}_trace gpurun_out/${TAG}_grbm > ${O}_lds_summary.md 2>${O}_lds_summary.err
+    rm -f profiles/${TAG}_l_pmc_summary.json; rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_grbm
+    grep -i "dw\|class\|stem" ${O}_lds_summary.md | cut -c1-200
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;
