@@ -57,6 +57,12 @@ constexpr int DWM_RS = DWM_RS_;  // raw-row ring depth
 #define DWM_TSKEW_ 32
 #endif
 constexpr int DWM_TSKEW = DWM_TSKEW_;
+// pad (bytes) behind a pixel of the output staging buffer.  A staging ds_write_b16 writes, for 4 pixels (lane & 3), the 16 channels of the wave
+// (32-B runs): with 16 B of pad (rounds 2-4) consecutive pixels' runs overlap by half in the 128-B bank window (0, 16, 32, 48), with 32 B they
+// tile it (0, 32, 64, 96).  -DDWM_OPAD_=16 restores the old pitch (A/B).
+#ifndef DWM_OPAD_
+#define DWM_OPAD_ 32
+#endif
 #ifndef DWM_ABL                  // timing-only ablations (wrong results; bit 0: no transposing writes, 1: no staging writes, 2: no per-row barrier,
                                  // 3: no MFMAs, 4: no output stores, 5: no LDS-DMA inside the row loop, 6: no LDS reads inside the row loop,
                                  // 7: ONE output staging buffer (racy) - with -DDWM_RS_=5 the deeper ring in the same LDS)
@@ -66,7 +72,7 @@ constexpr int DWM_TSKEW = DWM_TSKEW_;
 // or 6 (96 channels: with C = 96 the whole row segment of the strip is contiguous in memory)
 template <int NW> struct DwmCfg {
     static constexpr int CW = 16 * NW, PXB = CW * 2;          // channels / bytes per pixel of the workgroup's block
-    static constexpr int OPX = PXB + 16;                      // output staging: one pixel + 16 B pad (the 4 pixels of one ds_write_b16 on 4 bank groups)
+    static constexpr int OPX = PXB + DWM_OPAD_;               // output staging: one pixel + pad (the 4 pixels of one ds_write_b16 on 4 disjoint bank groups)
     static constexpr int HALO = 64 * PXB;                     // byte offset of the halo pixels inside a raw row
     static constexpr int RAWB = 72 * PXB, OB = 64 * OPX, TB = (16 * DWM_P + DWM_TSKEW) * 2;       // TB: one transposed image (+ the skew gap between its channel halves); two per wave
     static constexpr int NOB = (DWM_ABL & 128) ? 1 : 2;

@@ -224,10 +224,10 @@ import json
 d=json.load(open("${O}_bench_${label}.json")); print("${label}", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k in ("dw7", "dw3", "ffn_fused", "stem", "dw_down")})
 PY
     }
-    run_bench skew FVHD_LIB=ml_fastvlm_amd/libfvhd.so
-    run_bench noskew FVHD_LIB=ml_fastvlm_amd/libfvhd_ts0.so
-    run_bench skew2 FVHD_LIB=ml_fastvlm_amd/libfvhd.so
-    run_bench noskew2 FVHD_LIB=ml_fastvlm_amd/libfvhd_ts0.so
+    run_bench ${AB_A:-skew} FVHD_LIB=ml_fastvlm_amd/libfvhd.so
+    run_bench ${AB_B:-noskew} FVHD_LIB=ml_fastvlm_amd/libfvhd_${AB_LIB:-ts0}.so
+    run_bench ${AB_A:-skew}2 FVHD_LIB=ml_fastvlm_amd/libfvhd.so
+    run_bench ${AB_B:-noskew}2 FVHD_LIB=ml_fastvlm_amd/libfvhd_${AB_LIB:-ts0}.so
     CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-ttft"
     for pass in trace grbm; do
         extra=""; [ "$pass" = grbm ] && extra="--pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
