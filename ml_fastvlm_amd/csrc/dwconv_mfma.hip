@@ -57,11 +57,11 @@ constexpr int DWM_RS = DWM_RS_;  // raw-row ring depth
 #define DWM_TSKEW_ 32
 #endif
 constexpr int DWM_TSKEW = DWM_TSKEW_;
-// pad (bytes) behind a pixel of the output staging buffer.  A staging ds_write_b16 writes, for 4 pixels (lane & 3), the 16 channels of the wave
-// (32-B runs): with 16 B of pad (rounds 2-4) consecutive pixels' runs overlap by half in the 128-B bank window (0, 16, 32, 48), with 32 B they
-// tile it (0, 32, 64, 96).  -DDWM_OPAD_=16 restores the old pitch (A/B).
+// pad (bytes) behind a pixel of the output staging buffer: 16.  (Round 5 measured 32 - the four pixels' 32-B runs of a staging ds_write_b16 then
+// tile the 128-B bank window instead of overlapping by half: SQ_LDS_BANK_CONFLICT of the class 11.0 % -> 15.2 %, time unchanged,
+// profiles/r05_dw7_tskew_ab.log - so 16 stays; -DDWM_OPAD_=32 rebuilds the experiment.)
 #ifndef DWM_OPAD_
-#define DWM_OPAD_ 32
+#define DWM_OPAD_ 16
 #endif
 #ifndef DWM_ABL                  // timing-only ablations (wrong results; bit 0: no transposing writes, 1: no staging writes, 2: no per-row barrier,
                                  // 3: no MFMAs, 4: no output stores, 5: no LDS-DMA inside the row loop, 6: no LDS reads inside the row loop,
