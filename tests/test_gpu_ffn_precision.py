@@ -115,6 +115,15 @@ def test_audit_finds_the_saturating_block_and_the_switch_restores_parity():
     lims = [ctx.range_guard_limit(i) for i in range(len(ctx.steps())) if ctx.ffn_precision(i) >= 0]
     print(f"range-guard limits on max|A| for the mild weights: {min(lims):.0f} .. {max(lims):.0f}")
     assert len(lims) == 38 and min(lims) > 1000.0, "sane weights leave three orders of magnitude of headroom"
+    # the limit is the documented formula (include/fvhd.h "range guard"): (2^17 - max|b1|) / max_j L1(bf16(W1) row j) on max|A|
+    mild = synth.synthetic_state_dict(1234, "mild")
+    for i, (kind, stage, block, *_r) in enumerate(ctx.steps()):
+        if ctx.ffn_precision(i) < 0:
+            continue
+        pre = f"network.{[0, 2, 4][stage]}.{block}.convffn"
+        w1 = mild[pre + ".fc1.weight"].flatten(1).to(torch.bfloat16).double()
+        want_lim = (131072.0 - mild[pre + ".fc1.bias"].abs().max().item()) / w1.abs().sum(1).max().item()
+        assert abs(ctx.range_guard_limit(i) - want_lim) <= 1e-5 * want_lim, (i, ctx.range_guard_limit(i), want_lim)
 
 
 def test_every_block_on_the_bf16_form_by_configuration():
