@@ -128,6 +128,22 @@ def test_gemm_streaming_kernel_random_shapes(seed):
     test_gemm_epilogues(M, N, K, rnd.choice([_lib.EPI_NONE, _lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_BIAS_LS_RESID]))
 
 
+def test_gemm_persistent_tile_loop_is_bit_identical():
+    """FVHD_GEMM_PERSIST=1 (round 5, opt-in: measured neutral): the streaming 256-row kernels as one workgroup per CU walking the tiles, the next
+    tile's first K tiles issued before the current tile's epilogue.  Same tiles, same K order: the outputs must be the BITS of the default
+    one-tile-per-workgroup launch, for every epilogue (tools/gemm_bits.py fingerprints, one process per setting: the switch is read once)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_bits.py"), "--quick"], env=dict(os.environ, FVHD_GEMM_PERSIST=mode),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["out"]
+    assert len(outs["0"]) >= 7 and outs["0"] == outs["1"], {k: (outs["0"][k], outs["1"].get(k)) for k in outs["0"] if outs["0"][k] != outs["1"].get(k)}
+
+
 def test_gemm_inplace_residual_and_f32_out():
     M, N, K = 200, 384, 1536
     A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)

@@ -25,7 +25,16 @@ SHAPES = [  # (M, N, K, epilogue): 0 none, 1 bias, 2 bias+gelu, 3 bias+ls+resid,
 ]
 
 
+QUICK = [  # --quick: shapes with more tiles than CUs on the streaming 256-row kernels (what FVHD_GEMM_PERSIST=1 turns into a tile loop), every epilogue
+    (32768, 2304, 768, 0), (16384, 3072, 768, 2), (32768, 768, 768, 3), (32768, 896, 896, 1), (32768, 768, 768, 2), (2304, 9728, 896, 5), (32768, 1024, 512, 4),
+]
+
+
 def main():
+    global SHAPES
+    if "--quick" in sys.argv:
+        sys.argv.remove("--quick")
+        SHAPES = QUICK
     if len(sys.argv) > 1 and sys.argv[1] == "--diff":
         a, b = (json.load(open(f)) for f in sys.argv[2:4])
         bad = [k for k in a["out"] if a["out"][k] != b["out"].get(k)]
