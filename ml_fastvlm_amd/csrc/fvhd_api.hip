@@ -1264,8 +1264,8 @@ int fvhd_op_dw7_amax(fvhd_stream_t st, const void* x, void* y, const float* w, c
         if (!fvhd_dw7_mfma_supported(B, H, W, C, 1)) return fail("fvhd_op_dw7_amax: shape not supported by the matrix-core kernel");
         e = fvhd_launch_dw7_mfma((hipStream_t)st, x, y, w, bias, B, H, W, C, (unsigned*)amax_bits);
     } else {
-        // (batch_invariant = 0 and a shape below the matrix-core kernel's fill rule would still pick it: force the VALU kernel through W < 24?
-        //  no - the dispatcher takes the matrix-core kernel only when fvhd_dw7_mfma_supported(..., 0) holds; tests pass small batches here)
+        // the dispatcher of fvhd_launch_dwconv hands a shape to the matrix-core kernel exactly when fvhd_dw7_mfma_supported(..., 0) holds: refuse
+        // those here, so that "mfma = 0" always means the VALU kernel ran
         if (fvhd_dw7_mfma_supported(B, H, W, C, 0)) return fail("fvhd_op_dw7_amax: this shape dispatches to the matrix-core kernel (pass mfma = 1)");
         e = fvhd_launch_dwconv((hipStream_t)st, x, y, w, bias, B, H, W, C, 7, 1, 1, 0, 0, (unsigned*)amax_bits);
     }
