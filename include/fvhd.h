@@ -63,7 +63,9 @@ void fvhd_destroy(fvhd_ctx* ctx);
  * synchronises the device, frees and re-allocates the arena and drops the cached graphs - the only place where the library
  * synchronises.  Implicit growth inside fvhd_encode* / fvhd_project is refused while the caller's stream is being captured;
  * fvhd_reserve itself takes no stream and must not be called while ANY stream of the device is capturing (it synchronises the
- * device, which invalidates a capture): reserve before capturing.  Every entry point
+ * device, which invalidates a capture): reserve before capturing.  An arena that a caller's capture has recorded pointers into (an
+ * fvhd_encode* / fvhd_project call made while the caller's stream was capturing) is retired instead of freed when a later, larger batch
+ * replaces it: the caller's graph keeps replaying on valid memory until fvhd_destroy (round 5).  Every entry point
  * that takes a context runs on the context's device and restores the caller's current device before returning. */
 int fvhd_reserve(fvhd_ctx* ctx, int max_batch);
 
