@@ -384,15 +384,17 @@ done:
 // is the better choice (B = 1, C = 96: 18.8 vs 24.4 us)
 #ifdef FVHD_DEBUG_KNOBS
 static int g_dwm_rc = 0;                                     // > 0: rows per chunk forced (tools/bench_ops.py dw7small)
+static int g_dwm_nw = 0;                                     // 6: the 96-channel workgroup wherever C % 96 == 0 (tools/bench_ops.py dw7nw)
 extern "C" void fvhd_debug_set_dwm_rc(int rc) { g_dwm_rc = rc; }
+extern "C" void fvhd_debug_set_dwm_nw(int nw) { g_dwm_nw = nw; }
 #else
-static constexpr int g_dwm_rc = 0;
+static constexpr int g_dwm_rc = 0, g_dwm_nw = 0;
 #endif
 
 static int dwm_rows_per_chunk(int B, int H, int W, int C)
 {
     if (g_dwm_rc > 0) return g_dwm_rc;
-    const int nw = C % 64 == 0 ? 4 : 6;
+    const int nw = (C % 64 == 0 && !(g_dwm_nw == 6 && C % 96 == 0)) ? 4 : 6;
     const long long per_row_chunk = (long long)B * (C / (16 * nw)) * ((W + 63) / 64);
     if (per_row_chunk * ((H + 31) / 32) >= 192) return 32;
     if (per_row_chunk * ((H + 15) / 16) >= 192) return 16;
@@ -433,6 +435,7 @@ extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force)
 extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax)
 {
     if (!fvhd_dw7_mfma_supported(B, H, W, C, 1)) return (int)hipErrorInvalidValue;
-    if (amax) return C % 64 == 0 ? launch_dwm<4, true>(st, x, y, w, bias, B, H, W, C, amax) : launch_dwm<6, true>(st, x, y, w, bias, B, H, W, C, amax);
-    return C % 64 == 0 ? launch_dwm<4, false>(st, x, y, w, bias, B, H, W, C, nullptr) : launch_dwm<6, false>(st, x, y, w, bias, B, H, W, C, nullptr);
+    const bool nw4 = C % 64 == 0 && !(g_dwm_nw == 6 && C % 96 == 0);
+    if (amax) return nw4 ? launch_dwm<4, true>(st, x, y, w, bias, B, H, W, C, amax) : launch_dwm<6, true>(st, x, y, w, bias, B, H, W, C, amax);
+    return nw4 ? launch_dwm<4, false>(st, x, y, w, bias, B, H, W, C, nullptr) : launch_dwm<6, false>(st, x, y, w, bias, B, H, W, C, nullptr);
 }

@@ -140,6 +140,28 @@ def bench_dw7cfg():
     raw.fvhd_debug_set_dw7_cfg(1)
 
 
+def bench_dw7nw():
+    """matrix-core dw7x7: the 64-channel workgroup (4 waves, 2 per CU) against the 96-channel one (6 waves, 1 per CU) at C = 192 / 384"""
+    raw = _knobs()
+    for nw in (0, 6, 0, 6):
+        raw.fvhd_debug_set_dwm_nw(nw)
+        print(f"--- dw7 matrix-core kernel, {'default workgroup' if nw == 0 else '96-channel workgroup wherever C % 96 == 0'}")
+        _bench_dw(32, only_k7=True)
+    for Cc, H, B in ((192, 64, 2), (384, 70, 2), (384, 64, 32)):
+        x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+        w = torch.randn(49, Cc, device=DEV) / 7
+        bias = torch.randn(Cc, device=DEV)
+        outs = []
+        for nw in (0, 6):
+            raw.fvhd_debug_set_dwm_nw(nw)
+            y = torch.full((B, H, H, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
+            _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 7, 1, 1, 0))
+            torch.cuda.synchronize()
+            outs.append(y.clone())
+        print(f"dw7 64- vs 96-channel workgroup C={Cc} H={H} B={B}: equal {bool(torch.equal(outs[0], outs[1]))}")
+    raw.fvhd_debug_set_dwm_nw(0)
+
+
 def bench_dw7small():
     """dw7x7 stride 1 at the TTFT batch sizes: VALU kernel, default dispatch, and the matrix-core kernel with forced rows per chunk"""
     raw = _knobs()
@@ -291,4 +313,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw7nw": bench_dw7nw, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn}[w]()
