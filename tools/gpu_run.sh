@@ -237,6 +237,23 @@ PY
     rm -f profiles/${TAG}_l_pmc_summary.json; rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_grbm
     grep -i "dw\|class\|stem" ${O}_lds_summary.md | cut -c1-200
     ;;
+r5g)        # round 5: dw7 prologue order (first rows in flight before the tap loads) - digests and launch times under both libraries, same box
+    for rep in 1 2; do
+        for lib in "" _${AB_LIB:-pre}; do
+            echo "--- libfvhd${lib}.so (pass $rep)" | tee -a ${O}_dw7_bits.log
+            FVHD_LIB=ml_fastvlm_amd/libfvhd${lib}.so timeout 200 python tools/dw7_bits.py --time 2>&1 | grep "digest\|time" | tee -a ${O}_dw7_bits.log > /dev/null
+        done
+    done
+    python - <<PY
+import re
+txt = open("${O}_dw7_bits.log").read().split("--- ")[1:]
+dig = [[l for l in t.splitlines() if l.startswith("digest")] for t in txt]
+print("digests identical across libraries and passes:", all(d == dig[0] for d in dig), len(dig[0]))
+tm = [[l for l in t.splitlines() if l.startswith("time")] for t in txt]
+for rows in zip(*tm):
+    print(rows[0][:24], " | ".join(r.split(":")[1].strip() for r in rows), " (new, pre, new, pre)")
+PY
+    ;;
 pmc)        # rocprofv3 kernel trace + the PMC passes of the final binary
     bash tools/run_pmc.sh ${TAG}
     ;;
