@@ -220,6 +220,18 @@ int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* 
  * mfma = 1: for W % 64 != 0 a superset of the image, computed from the zero padding) - as the fp32 bit pattern of a non-negative number
  * (combined with atomicMax: unsigned order = numeric order), taken from the fp32 accumulators before the rounding to bf16.  mfma = 0 is an error
  * for shapes the dispatcher gives to the matrix-core kernel, mfma = 1 for shapes that kernel does not take. */
+/* RepMixer dw3x3 (+ bias) followed by the ConvFFN's dw7x7 (+ folded BatchNorm bias) in ONE launch (round 6, csrc/dwconv_fused.hip;
+ * mci.py:808-811 -> :920-921): x [B,H,W,C] -> y = dw3x3(x) + b3 [B,H,W,C] (the block's residual stream, written once) and
+ * a = dw7x7(y) + b7 [B,H,W,C], all NHWC bf16; w3 fp32 [9][C], w7 fp32 [49][C], b3 / b7 fp32 [C] or NULL.  Both convolutions run on the
+ * 16-block 4x4x4 bf16 MFMA: the 3x3 with every tap split into two bf16 halves (16 mantissa bits - the re-parameterised centre tap is
+ * 1 + eps), the 7x7 exactly as fvhd_op_dw7_mfma (taps rounded to bf16; the same bits as that entry point given the same y).
+ * amax_bits: NULL or FVHD_AMAX_SLOTS words (zeroed by the caller) receiving max |a| as in fvhd_op_dw7_amax(mfma = 1).
+ * Needs C % 64 == 0, W % 4 == 0, W >= 16; anything else is an error.  The tower takes this kernel for a RepMixerBlock by itself once
+ * the launch fills the chip (fvhd_dw3_dw7_supported(..., 0)); never under fvhd_set_batch_invariant. */
+int fvhd_op_dw3_dw7(fvhd_stream_t stream, const void* x, void* y, void* a, const float* w3, const float* b3, const float* w7,
+                    const float* b7, int B, int H, int W, int C, void* amax_bits);
+/* 1 when fvhd_op_dw3_dw7 takes the shape (force != 0) / when the tower picks it by itself (force == 0) */
+int fvhd_dw3_dw7_supported(int B, int H, int W, int C, int force);
 #define FVHD_AMAX_SLOTS 64
 int fvhd_op_dw7_amax(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, int mfma,
                      void* amax_bits);

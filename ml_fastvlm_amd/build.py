@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libfvhd.so")
-SOURCES = ["dwconv.hip", "dwconv_mfma.hip", "gemm.hip", "attention.hip", "stem_head.hip", "ffn_fused.hip", "splice.hip", "preprocess.hip", "llm.hip", "llm_api.hip", "fvhd_api.hip"]
+SOURCES = ["dwconv.hip", "dwconv_mfma.hip", "dwconv_fused.hip", "gemm.hip", "attention.hip", "stem_head.hip", "ffn_fused.hip", "splice.hip", "preprocess.hip", "llm.hip", "llm_api.hip", "fvhd_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-fno-gpu-rdc"]
@@ -40,7 +40,9 @@ VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=200000"] + NOPK,
                "attention.hip": NOPK + VGPR_FORM, "llm.hip": NOPK + VGPR_FORM, "stem_head.hip": VGPR_FORM,
                # dwconv_mfma.hip: 7 x 84 hand-placed MFMA slots, every register-array index compile-time (768 B/lane of scratch otherwise)
-               "dwconv_mfma.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+               "dwconv_mfma.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+               # dwconv_fused.hip: the same row loops (3 x 60 producer slots, 7 x 84 consumer slots)
+               "dwconv_fused.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 def _hipcc() -> str:

@@ -21,6 +21,7 @@ int fvhd_launch_dw7_mfma(hipStream_t, const void*, void*, const float*, const fl
 int fvhd_launch_preprocess(hipStream_t, const void*, int, int, long, int, int, unsigned, const int*, const int*, int, const int*, const int*, int, int, int,
                            void*, const float*, int, void*, int);
 int fvhd_dw7_mfma_supported(int, int, int, int, int);
+int fvhd_launch_dw3_dw7(hipStream_t, const void*, void*, void*, const float*, const float*, const float*, const float*, int, int, int, int, unsigned*);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_gemm_splitk_plan(int, int, int);
 int fvhd_launch_gemm_splitk_ls(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, float*, int, int, int, int);
@@ -1339,6 +1340,18 @@ int fvhd_op_se_head(fvhd_stream_t st, const void* y, float* pooled, float* scale
 {
     int e = fvhd_launch_se_head((hipStream_t)st, y, pooled, scale, wr, br, we, be, out, out_dtype, B, T, C, RD);
     return e ? hip_fail("fvhd_op_se_head", (hipError_t)e) : 0;
+}
+
+int fvhd_op_dw3_dw7(fvhd_stream_t st, const void* x, void* y, void* a, const float* w3, const float* b3, const float* w7, const float* b7,
+                    int B, int H, int W, int C, void* amax_bits)
+{
+    if (!x || !y || !a || !w3 || !w7) return fail("fvhd_op_dw3_dw7: NULL pointer");
+    if (x == y || x == a || y == a) return fail("fvhd_op_dw3_dw7: x, y and a must be three distinct buffers");
+    if (!fvhd_dw3_dw7_supported(B, H, W, C, 1))
+        return fail("fvhd_op_dw3_dw7: needs C % 64 == 0, W % 4 == 0, W >= 16 and an image below 2 GiB (got B=" + std::to_string(B) + " H=" +
+                    std::to_string(H) + " W=" + std::to_string(W) + " C=" + std::to_string(C) + ")");
+    int e = fvhd_launch_dw3_dw7((hipStream_t)st, x, y, a, w3, b3, w7, b7, B, H, W, C, (unsigned*)amax_bits);
+    return e ? hip_fail("fvhd_op_dw3_dw7", (hipError_t)e) : 0;
 }
 
 int fvhd_op_dw7_mfma(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)

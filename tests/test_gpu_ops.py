@@ -393,6 +393,73 @@ def test_dwconv_matrix_core_kernel_random_shapes(seed):
     test_dwconv(7, 1, 1, 0, Cin, H, W, B, force_mfma=True)
 
 
+def _repmixer_taps(C, seed):
+    """dw3x3 taps shaped like a re-parameterised RepMixer (mci.py:819-859): identity + small branches, i.e. a centre tap of 1 + eps -
+    the case a single bf16 tap would get wrong by 2^-9 of x"""
+    w = _rand(C, 1, 3, 3, seed=seed, scale=0.15)
+    w[:, 0, 1, 1] += 1.0
+    return w
+
+
+@pytest.mark.parametrize("C,H,W,B,amax", [
+    (64, 40, 64, 2, False),      # one strip, chunks of 16 rows (the last ragged)
+    (192, 33, 128, 2, True),     # two strips, three channel blocks, ragged last chunk, with the range guard's maximum
+    (128, 70, 96, 1, False),     # second strip 32 px wide (masked segments), 5 chunks
+    (64, 3, 64, 1, True),        # fewer rows than the 7x7 has taps: every A row comes from the consumer's tail loop
+    (64, 1, 32, 2, False),       # a single row
+    (384, 64, 64, 3, False),     # stage 2 of the 1024^2 tower
+    (64, 24, 20, 2, False),      # W % 64 = 20: stage 2 of a 320^2 tower
+    (128, 17, 16, 2, True),      # the narrowest map
+    (64, 50, 132, 1, False),     # third strip 4 px wide
+    (192, 128, 128, 12, True),   # large enough for the tower's own dispatch (32-row chunks)
+])
+def test_dw3_dw7_fused_kernel(C, H, W, B, amax):
+    """fvhd_op_dw3_dw7 (csrc/dwconv_fused.hip): RepMixer dw3x3 -> ConvFFN dw7x7 in one launch.
+    y against the fp32 conv on the same bf16 inputs (the usual op tolerance) AND against the two-kernel route's y (fp32 taps on the VALU):
+    hi + lo bf16 taps carry 16 mantissa bits, i.e. the two fp32 sums agree to ~2^-17 of the operand magnitude (inputs are O(1): 3e-5
+    absolute, which matters only where x + conv cancels to ~0) and may land on either side of a bf16 rounding boundary - one ulp, in under
+    1 % of the elements.  a must be the BITS of fvhd_op_dw7_mfma run on the kernel's own y."""
+    lib = _lib.load()
+    x = _bf(_rand(B, C, H, W, seed=21))
+    w3, b3 = _repmixer_taps(C, 22), _rand(C, seed=23, scale=0.2)
+    w7, b7 = _rand(C, 1, 7, 7, seed=24, scale=1.0 / 7), _rand(C, seed=25, scale=0.2)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y, a, y2, a2 = (torch.full((B, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(4))
+    w3d, b3d, w7d, b7d = _pack_dw(w3).to(DEV), b3.to(DEV), _pack_dw(w7).to(DEV), b7.to(DEV)
+    bits = torch.zeros(64, dtype=torch.int32, device=DEV)
+    assert lib.fvhd_dw3_dw7_supported(B, H, W, C, 1) == 1
+    _lib.check(lib.fvhd_op_dw3_dw7(_stream(), _p(xn), _p(y), _p(a), _p(w3d), _p(b3d), _p(w7d), _p(b7d), B, H, W, C, _p(bits) if amax else None), "dw3_dw7")
+    _lib.check(lib.fvhd_op_dwconv(_stream(), _p(xn), _p(y2), _p(w3d), _p(b3d), B, H, W, C, 3, 1, 1, 0), "dw3")
+    _lib.check(lib.fvhd_op_dw7_mfma(_stream(), _p(y), _p(a2), _p(w7d), _p(b7d), B, H, W, C), "dw7 mfma")
+    torch.cuda.synchronize()
+    want_y = F.conv2d(x.float(), w3, b3, padding=1, groups=C)
+    _close(y.permute(0, 3, 1, 2), want_y, what="dw3_dw7: y")
+    yf, y2f = y.float(), y2.float()
+    differ = (yf != y2f)
+    assert ((yf - y2f).abs() <= 2.0 ** -7 * torch.maximum(yf.abs(), y2f.abs()) + 3e-5).all(), "y differs from the fp32-tap kernel by more than one bf16 ulp"
+    assert differ.float().mean().item() < 1e-2, f"{differ.float().mean().item():.3%} of y differs from the fp32-tap kernel"
+    assert torch.equal(a.view(torch.int16), a2.view(torch.int16)), "a is not the matrix-core dw7x7 of the kernel's own y"
+    want_a = F.conv2d(y.float().cpu().permute(0, 3, 1, 2), _bf(w7).float(), b7, padding=3, groups=C)
+    _close(a.permute(0, 3, 1, 2), want_a, what="dw3_dw7: a")
+    if amax:
+        Wext = -(-W // 64) * 64
+        ye = F.pad(y.float().cpu().permute(0, 3, 1, 2), (0, Wext - W))
+        want_m = F.conv2d(ye, _bf(w7).float(), b7, padding=3, groups=C)[..., :Wext].abs().max().item()
+        got_m = bits.view(torch.float32).max().item()
+        assert abs(got_m - want_m) <= 1e-5 * want_m, (got_m, want_m)
+
+
+def test_dw3_dw7_rejects_shapes_it_does_not_take():
+    lib = _lib.load()
+    x = torch.zeros(1, 8, 64, 64, dtype=torch.bfloat16, device=DEV)
+    y, a = torch.zeros_like(x), torch.zeros_like(x)
+    w3, w7 = torch.zeros(9, 96, device=DEV), torch.zeros(49, 96, device=DEV)
+    assert lib.fvhd_op_dw3_dw7(_stream(), _p(x), _p(y), _p(a), _p(w3), None, _p(w7), None, 1, 8, 64, 96, None) != 0     # C = 96
+    assert lib.fvhd_op_dw3_dw7(_stream(), _p(x), _p(y), _p(a), _p(w3), None, _p(w7), None, 1, 8, 18, 64, None) != 0     # W % 4
+    assert lib.fvhd_op_dw3_dw7(_stream(), _p(x), _p(x), _p(a), _p(w3), None, _p(w7), None, 1, 8, 64, 64, None) != 0     # y aliases x
+    assert lib.fvhd_dw3_dw7_supported(1, 64, 64, 384, 0) == 0 and lib.fvhd_dw3_dw7_supported(32, 64, 64, 384, 0) == 1
+
+
 def test_dw7_mfma_rejects_shapes_it_does_not_take():
     lib = _lib.load()
     x = torch.zeros(1, 8, 32, 64, dtype=torch.bfloat16, device=DEV)

@@ -301,6 +301,32 @@ def bench_gemmsmall():
     raw.fvhd_debug_set_gemm_v2(1)
 
 
+def bench_dw37(B=32):
+    """RepMixer dw3x3 -> ConvFFN dw7x7: the two-kernel route against the fused launch (csrc/dwconv_fused.hip), interleaved rounds on one box;
+    with the debug library also a sweep of the fused kernel's rows per chunk (fvhd_debug_set_fz_rc)"""
+    raw = C.CDLL(_lib.LIB_PATH)
+    shapes = [(Cc, H) for Cc, H in ((192, 128), (384, 64), (64, 256)) if lib.fvhd_dw3_dw7_supported(B, H, H, Cc, 1)]
+    for Cc, H in shapes:
+        x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+        y, a = torch.empty_like(x), torch.empty_like(x)
+        w3, b3 = torch.randn(9, Cc, device=DEV) * 0.15, torch.randn(Cc, device=DEV) * 0.2
+        w3[4] += 1.0
+        w7, b7 = torch.randn(49, Cc, device=DEV) / 7, torch.randn(Cc, device=DEV) * 0.2
+        two = lambda: (_lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w3), p(b3), B, H, H, Cc, 3, 1, 1, 0)),
+                       _lib.check(lib.fvhd_op_dwconv(stream(), p(y), p(a), p(w7), p(b7), B, H, H, Cc, 7, 1, 1, 0)))
+        one = lambda: _lib.check(lib.fvhd_op_dw3_dw7(stream(), p(x), p(y), p(a), p(w3), p(b3), p(w7), p(b7), B, H, H, Cc, None))
+        by = 2.0 * x.numel()
+        rounds = [(timeit(two, iters=30), timeit(one, iters=30)) for _ in range(3)]
+        t2, t1 = min(r[0] for r in rounds), min(r[1] for r in rounds)
+        print(f"dw3+dw7 C={Cc:4d} {H}x{H} B={B}: two launches {t2*1e6:7.1f} us ({4*by/t2/1e12:.2f} TB/s of 4 passes)   fused {t1*1e6:7.1f} us "
+              f"({3*by/t1/1e12:.2f} TB/s of 3 passes)   rounds {[(round(r[0]*1e6, 1), round(r[1]*1e6, 1)) for r in rounds]}")
+        if hasattr(raw, "fvhd_debug_set_fz_rc"):
+            for rc in (16, 22, 32, 43, 64):
+                raw.fvhd_debug_set_fz_rc(rc)
+                print(f"    rows per chunk {rc:3d}: {timeit(one, iters=30)*1e6:7.1f} us")
+            raw.fvhd_debug_set_fz_rc(0)
+
+
 def bench_attn(B=32):
     for N, Cc in ((1024, 768), (256, 1536), (2304, 768), (576, 1536)):
         qkv = torch.randn(B * N, 3 * Cc).to(DEV, torch.bfloat16)
@@ -313,4 +339,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw7nw": bench_dw7nw, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw7nw": bench_dw7nw, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn, "dw37": bench_dw37}[w]()

@@ -101,6 +101,11 @@ final)      # evidence of the final binary: bench line, small batches, PMC passe
     timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_ttft_trace -o ttft -- python bench.py --ttft --steps 4 --warmup 1 > gpurun_out/${TAG}_ttft_trace.log 2>&1
     python tools/rocpd_summary.py gpurun_out/${TAG}_ttft_trace/ttft_results.db > ${O}_ttft_kernel_trace.md 2>&1; rm -rf gpurun_out/${TAG}_ttft_trace; head -30 ${O}_ttft_kernel_trace.md | cut -c1-160
     ;;
+r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
+    timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
+    timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
+    FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37_rc.log
+    ;;
 r5a)        # round 5, first call: whole GPU suite (all failures, not -x), the driver's line, GEMM layout A/B (bits + time), WRITE_SIZE of the GEMM classes
     timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --durations=8 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -30 ${O}_pytest.log | cut -c1-300
     timeout 900 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cut -c1-400 ${O}_bench.json; tail -3 ${O}_bench.err
