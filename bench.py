@@ -39,12 +39,15 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md "Chip-level para
 HBM_PEAK_GBS = 8000.0         # HBM3E spec, same table
 
 
-def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True):
+def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True, dw_mix=None):
     """Per kernel class: (FLOPs, HBM bytes) of ONE step at batch B, counted algorithmically
-    (2*MAC; each activation tensor once in + once out per launch, bf16; weights once)."""
+    (2*MAC; each activation tensor once in + once out per launch, bf16; weights once).
+    dw_mix(H, C) -> bool: the RepMixerBlocks whose dw3x3 and dw7x7 run as ONE launch (class "dw_mix", round 6).  That class carries
+    the algorithmic figures of BOTH convolutions (4 tensor passes, although the launch moves 3): the conv-stage total stays the
+    SURVEY 8d figure whichever way the kernels are grouped."""
     from ml_fastvlm_amd import fastvithd_spec as spec
     w = {k: [0.0, 0.0] for k in ("stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv",
-                                 "gemm_proj", "layernorm", "attention", "head", "projector", "ffn_fused")}
+                                 "gemm_proj", "layernorm", "attention", "head", "projector", "ffn_fused", "dw_mix")}
 
     def add(k, flops, bytes_):
         w[k][0] += flops
@@ -64,8 +67,11 @@ def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True):
         M = B * H * H
         if spec.HAS_CPE[s]:
             add("dw7", 2.0 * M * C * 49, 4.0 * M * C)
+        mix = spec.TOKEN_MIXERS[s] == "repmixer" and dw_mix is not None and dw_mix(H, C)
         for _ in range(depth):
-            if spec.TOKEN_MIXERS[s] == "repmixer":
+            if mix:
+                add("dw_mix", 2.0 * M * C * (9 + 49), 8.0 * M * C)
+            elif spec.TOKEN_MIXERS[s] == "repmixer":
                 add("dw3", 2.0 * M * C * 9, 4.0 * M * C)
             else:
                 add("layernorm", 8.0 * M * C, 4.0 * M * C)
@@ -73,7 +79,8 @@ def algorithmic_work(B: int, R: int, hidden: int, fused: bool = True):
                 N = H * H
                 add("attention", 4.0 * B * (C // 32) * N * N * 32, 2.0 * (M * 3 * C + M * C))
                 gemm("gemm_proj", M, C, C, resid=True)
-            add("dw7", 2.0 * M * C * 49, 4.0 * M * C)
+            if not mix:
+                add("dw7", 2.0 * M * C * 49, 4.0 * M * C)
             if fused and C <= 384:     # fc1 + GELU + fc2 + layer-scale + residual in one launch, hidden on chip
                 add("ffn_fused", 16.0 * M * C * C, 2.0 * (3 * M * C + 8 * C * C))
             else:
@@ -373,7 +380,10 @@ def main():
         torch.cuda.synchronize()
         prof = ctx.profile_read()
         ctx.profile_enable(False)
-        work = algorithmic_work(B, R, Hd, fused=prof.get("ffn_fused", (0, 0))[1] > 0)
+        from ml_fastvlm_amd import _lib as _fl
+        mixed = prof.get("dw_mix", (0, 0))[1] > 0              # the tower's own rule (fvhd_dw3_dw7_supported) when the class was launched at all
+        work = algorithmic_work(B, R, Hd, fused=prof.get("ffn_fused", (0, 0))[1] > 0,
+                                dw_mix=(lambda H_, C_: bool(_fl.load().fvhd_dw3_dw7_supported(B, H_, H_, C_, 0))) if mixed else None)
         table, total_ms = {}, 0.0
         for k, (ms, n) in prof.items():
             if n == 0:

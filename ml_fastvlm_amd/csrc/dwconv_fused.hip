@@ -56,51 +56,63 @@ struct FzCfg {
     static constexpr int TB = (16 * FZ_P + FZ_SK) * 2;                  // one [16 ch][P px] image (bytes)
     // raw x rows | transposed x (private per producer wave, 2 each) | y rows (producer -> consumer AND -> the y store, 2 per wave pair) |
     // A rows (consumer -> the A store, 2 per consumer wave): all three images have ONE layout, [wave][buffer][16 ch][P px]
-    static constexpr int OFF_TX = FZ_RS * RAWB, OFF_TY = OFF_TX + 8 * TB, OFF_OA = OFF_TY + 8 * TB;
-    static constexpr int LDS = OFF_OA + 8 * TB;
+    static constexpr int NTY = 3;                                        // y rows in flight per wave pair: written in iteration g, operands prefetched in g + 1, consumed in g + 2
+    static constexpr int OFF_TX = FZ_RS * RAWB, OFF_TY = OFF_TX + 8 * TB, OFF_OA = OFF_TY + 4 * NTY * TB;
+    static constexpr int OFF_Z = OFF_OA + 8 * TB;                       // one all-zero image: the operand image of an x row outside the picture
+    static constexpr int LDS = OFF_Z + TB;
 };
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
+
+// -DFZ_TRACE: cycle stamps (s_memtime) of a few row iterations of one producer and one consumer wave into a device array that
+// fvhd_debug_fz_trace copies out - a timing aid (the SMEM returns share lgkmcnt with the LDS reads: results of a trace build are not to be trusted)
+#ifdef FZ_TRACE
+__device__ unsigned long long fz_trace_buf[2 * 2 * 16 * 8];
+#define FZ_TS(i) asm volatile("s_memtime %0" : "=s"(ts[i]))
+#define FZ_TS_DUMP(role, it)                                                                                       \
+    if ((blockIdx.x == 0 || blockIdx.x == 77) && wq == 1 && (it) >= 9 && (it) < 25 && lane == 0) {                  \
+        unsigned long long* d = fz_trace_buf + ((((blockIdx.x == 77) * 2 + (role)) * 16 + ((it) - 9)) * 8);        \
+        for (int i_ = 0; i_ < 8; ++i_) d[i_] = ts[i_];                                                            \
+    }
+#else
+#define FZ_TS(i)
+#define FZ_TS_DUMP(role, it)
+#endif
 
 FVHD_DEV u16 fz_bf16_rne(float f) { unsigned u = __float_as_uint(f); u += 0x7fff + ((u >> 16) & 1); return (u16)(u >> 16); }
 FVHD_DEV float fz_bf16_f32(u16 h) { return __uint_as_float((unsigned)h << 16); }
 
-template <bool AMAX>
+template <bool AMAX, bool MASKALL>
 __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__ x, u16* __restrict__ y, u16* __restrict__ a,
                                                          const float* __restrict__ w3, const float* __restrict__ b3,
                                                          const float* __restrict__ w7, const float* __restrict__ b7,
-                                                         int H, int W, int C, int RC, int nstrip, int nchunk, unsigned* amax)
+                                                         int H, int W, int C, int nstrip, int rows_per_wg, int total_rows, unsigned* amax)
 {
+    // Work partition: the (image, strip) COLUMNS of H rows each are laid end to end and cut into equal runs of rows_per_wg output rows;
+    // a GROUP of C / 64 workgroups (adjacent block ids: one per 64-channel block, each with its own taps for the whole launch) marches down
+    // one run in step, one SEGMENT (= the part inside one column) after the other - so the 128-B pieces of a pixel's C channels are read
+    // and written by neighbouring CUs at about the same time (DRAM pages), and with one resident workgroup per CU every CU gets the same
+    // number of rows whatever B * strips is (B = 32 at C = 384: 32 columns of 64 rows over 42 groups of 6 = 49 rows each).
     using K = FzCfg;
     constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = FZ_RS, P = FZ_P, RAWB = K::RAWB, TBY = K::TB, TE = TBY / 2, SK = FZ_SK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wq = wv & 3;                                   // channel group of this wave (producer wq and consumer wq + 4 share it)
     const int blk = lane >> 2, q = lane & 3;
-    const int NCB = C / CW;
-    int L = blockIdx.x;
-    const int cb = L % NCB; L /= NCB;
-    const int strip = L % nstrip; L /= nstrip;
-    const int chunk = L % nchunk;
-    const int n = L / nchunk;
-    const int c0 = cb * CW + wq * 16, x0 = strip * SW, ylo = chunk * RC, yhi = min(H, ylo + RC);
     const unsigned img_bytes = (unsigned)H * W * C * 2, row_bytes = (unsigned)W * C * 2;
-    // y rows the 7x7 reads: [r_lo, r_hi) (all inside the image); x rows the 3x3 reads for them: r_lo - 1 .. r_hi (zero rows outside the image)
-    const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3), nrow = r_hi - r_lo, NP = nrow + 2;
-    const int ntail = max(0, yhi - max(ylo, r_hi - 3));      // output rows whose last input row lies below the image
+    const int NCB = C / CW, cb = (int)blockIdx.x % NCB, c0 = cb * CW + wq * 16;
+    int g0 = ((int)blockIdx.x / NCB) * rows_per_wg;
+    const int g1 = min(g0 + rows_per_wg, total_rows);
     char* raw = smem;                                        // [RS][64 interior px | 8 halo px][PXB]
-    auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + off); };
     // Whole-line stores of a finished row straight from its [ch][px] image (T_y for y, O_A for A), transposed by the LDS read:
     // ds_read_b64_tr_b16 gives lane l of a 16-lane group element j = element (l & 3) of the 8 bytes SOURCE lane 4 j + (l >> 2) & 3 addressed.
     // Source role of lane (group g, j = (lane >> 2) & 3, c = lane & 3): 4 consecutive pixels of channel 8 o + 4 hf + j, o = (4 g + c) & 7,
     // pixel quad 16 wq + 8 h + 4 ((4 g + c) >> 3); output role of lane (g, c = (lane >> 2) & 3, e = lane & 3): channels 8 o .. 8 o + 7
     // (two reads, hf = 0, 1) of pixel 16 wq + 8 h + 4 ((4 g + c) >> 3) + e - so one store instruction (h = 0, 1) moves 8 whole 128-B lines.
     const int ss = 4 * (lane >> 4) + (lane & 3), so = ss & 7, sj = (lane >> 2) & 3, sr = 8 * (so & 1) + sj;    // source: row inside wave (so >> 1)'s image, hf = 0
-    const unsigned trsrc = (unsigned)(((so >> 1) * 2 * TE + sr * P + SK * (sr >> 3) + 16 * wq + 4 * (ss >> 3)) * 2);   // bytes; + column offset, + 8 h px, + 4 P hf, + buffer
-    const int ds_ = 4 * (lane >> 4) + ((lane >> 2) & 3), dpx = x0 + 16 * wq + 4 * (ds_ >> 3) + (lane & 3);      // output role
-    const unsigned vst0 = goff(dpx, (ds_ & 7) * 16), oob0 = dpx < W ? 0u : 0x80000000u;
-    const unsigned vst1 = goff(dpx + 8, (ds_ & 7) * 16), oob1 = dpx + 8 < W ? 0u : 0x80000000u;
-    auto tr_row = [&](u32x4 (&o)[2], unsigned region_lds, int coloff, int buf) {       // the 2 x 2 transposing reads of this wave's 16 pixels
-        const unsigned a0 = region_lds + trsrc + (unsigned)((coloff + buf * TE) * 2);
+    const unsigned trsrc = (unsigned)((sr * P + SK * (sr >> 3) + 16 * wq + 4 * (ss >> 3)) * 2);   // bytes; + wave image (so >> 1), + column offset, + 8 h px, + 4 P hf, + buffer
+    const int ds_ = 4 * (lane >> 4) + ((lane >> 2) & 3), dpxr = 16 * wq + 4 * (ds_ >> 3) + (lane & 3);         // output role: strip pixel (h = 0), 16-B chunk ds_ & 7
+    auto tr_row = [&](u32x4 (&o)[2], unsigned region_lds, int nbuf, int coloff, int buf) {       // the 2 x 2 transposing reads of this wave's 16 pixels
+        const unsigned a0 = region_lds + trsrc + (unsigned)(((so >> 1) * nbuf * TE + coloff + buf * TE) * 2);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(size_t)(a0 + 16 * h));
@@ -109,14 +121,43 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             o[h] = u32x4{l2.x, l2.y, h2.x, h2.y};
         }
     };
+    float amx = 0.f;
 
     if (wv < 4) {
         // =========================================================== PRODUCER: x -> y (HBM) and y -> T_y (LDS)
         u16* T = (u16*)(smem + K::OFF_TX + wq * 2 * TBY);    // private: [2][16 ch][P px] transposed x rows
-        u16* TY = (u16*)(smem + K::OFF_TY + wq * 2 * TBY);   // shared with consumer wq + 4: [2][16 ch][P px] y rows
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)n * H * W * C), 0, img_bytes, 0x00020000);
-        const char* ximg = (const char*)(x + (size_t)n * H * W * C);
-
+        u16* TY = (u16*)(smem + K::OFF_TY + wq * K::NTY * TBY);   // shared with consumer wq + 4: [NTY][16 ch][P px] y rows
+        constexpr int ZREL = 0;                              // (placeholder: the zero image's offset is wave dependent, below)
+        (void)ZREL;
+        const int zrel = (K::OFF_Z - (K::OFF_TX + wq * 2 * TBY)) / 2;      // u16 index of the shared all-zero image relative to T
+        {
+            f32x4 z = {0, 0, 0, 0};
+            for (int i = lane; i < TBY / 16; i += 64) *(f32x4*)(smem + K::OFF_Z + i * 16) = z;       // every producer writes the same zeros
+            for (int i = lane; i < K::NTY * TBY / 16; i += 64) *(f32x4*)((char*)TY + i * 16) = z;
+        }
+        // ---- transposition raw row -> T (this lane's three 16-B chunks: T column 32 m + lane / 2, channel half lane & 1)
+        unsigned roff[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int col = 32 * m + (lane >> 1);
+            const int cc = min(col, IWX - 1), ip = cc - 4;
+            const int sub = wq * 32 + (lane & 1) * 16;
+            roff[m] = (unsigned)(cc < 4 ? K::HALO + cc * PXB + sub : cc >= 68 ? K::HALO + (cc - 64) * PXB + sub
+                                        : (ip >> 3) * 1024 + wq * 256 + (ip & 7) * 32 + (lane & 1) * 16);
+        }
+        auto tr_read = [&](u32x4 (&v)[3], int slot) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) v[m] = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
+        };
+        // ---- operand reads of one transposed x row: centre segment (8 B) + the two neighbour pixels (2 B each)
+        const u16* rd = T + blk * P + SK * (blk >> 3) + 4 * q;
+        unsigned sidebase = lds_addr(rd);
+        asm volatile("" : "+v"(sidebase));
+        int lofs[5], rofs[5];                                 // (t' = 0, q = 0) has no left pixel, (t' = 4, q = 3) no right one inside the row:
+#pragma unroll                                                // both read a finite in-row value; the y pixels they touch are never used
+        for (int t = 0; t < 5; ++t) { lofs[t] = 16 * t - ((t == 0 && q == 0) ? 0 : 1); rofs[t] = 16 * t + ((t == 4 && q == 3) ? 3 : 4); }
+        u16* tyw = TY + blk * P + SK * (blk >> 3) + 4 * q;
+        const unsigned raw_lds = lds_addr(raw);
         // ---- Toeplitz^T operands of this lane (channel blk, output pixel i = q of a segment), hi + lo halves of every tap:
         //   centre  [k] = tap(ky, kx = k - q + 1)                     (input pixel k of the SAME segment)
         //   side    [0] = tap(ky, 0) for q == 0 (left neighbour's last pixel), [1] = tap(ky, 2) for q == 3 (right neighbour's first)
@@ -134,201 +175,213 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             const u16 lh = fz_bf16_rne(vl), ll = fz_bf16_rne(vl - fz_bf16_f32(lh)), rh = fz_bf16_rne(vr), rl = fz_bf16_rne(vr - fz_bf16_f32(rh));
             tsh[ky] = s16x4{(short)lh, (short)rh, 0, 0}; tsl[ky] = s16x4{(short)ll, (short)rl, 0, 0};
         }
-        const float bv = b3 ? b3[c0 + blk] : 0.f;
-        f32x4 biasq = {bv, bv, bv, bv};
-        asm volatile("" : "+v"(biasq));
-        f32x4 acc[3][5];
+        const float bv3 = b3 ? b3[c0 + blk] : 0.f;
+        f32x4 biasq = {bv3, bv3, bv3, bv3};
+        // side operands {left pixel, right pixel, 0, 0}: five fixed register pairs whose upper halves stay zero for the whole kernel
+        s16x4 xs[5];
 #pragma unroll
-        for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-            for (int t = 0; t < 5; ++t) acc[sl][t] = biasq;
+        for (int t = 0; t < 5; ++t) { xs[t] = s16x4{0, 0, 0, 0}; asm volatile("" : "+v"(xs[t])); }
 
-        // ---- LDS-DMA of one x row (dw7_mfma_kernel's piece layout: 8 px x 128 B per 1-KiB piece, 16-B chunks stored
-        // [consumer wave][px][half] so that a wave's ds_read_b128 of its 32-B column is conflict-free; halo [4 left | 4 right][128 B])
-        const int ipx = x0 + 16 * wq + ((lane >> 1) & 7), ioff = (lane >> 4) * 32 + (lane & 1) * 16;
-        const unsigned vint0 = goff(ipx, ioff), vint1 = goff(ipx + 8, ioff);
-        const int hb = 256 * wq + 16 * (lane & 15), hp = hb / PXB;
-        const unsigned vhalo = goff(hp < 4 ? x0 - 4 + hp : x0 + 60 + hp, hb % PXB);
-        const unsigned raw_lds = lds_addr(raw);
-        auto dma = [&](int xr, int slot) {
-            const char* rb = ximg + (size_t)min(max(xr, 0), H - 1) * row_bytes;
-            const unsigned d0 = raw_lds + slot * RAWB + 2048 * wq, dh = raw_lds + slot * RAWB + K::HALO + 256 * wq;
-            unsigned keep; unsigned long long ex;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
-                         "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
-                         "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
-                         "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep), "=&s"(ex) : "v"(vint0), "v"(vint1), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb) : "memory", "scc");
-        };
-        // ---- transposition raw row -> T (this lane's three 16-B chunks: T column 32 m + lane / 2, channel half lane & 1)
-        unsigned roff[3], tdst[3];
+        while (g0 < g1) {
+            const int col = g0 / H, ylo = g0 - col * H, yhi = min(H, ylo + (g1 - g0));
+            const int n = col / nstrip, strip = col - n * nstrip, x0 = strip * SW;
+            g0 += yhi - ylo;
+            // y rows the 7x7 reads: [r_lo, r_hi) (all inside the image); x rows the 3x3 reads for them: r_lo - 1 .. r_hi (zero rows outside the image)
+            const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3), nrow = r_hi - r_lo, NP = nrow + 2;
+            const int ntail = max(0, yhi - max(ylo, r_hi - 3));      // output rows whose last input row lies below the image
+            auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + off); };
+            const char* ximg = (const char*)(x + (size_t)n * H * W * C);
+            asm volatile("" : "+v"(biasq));
+            f32x4 acc[3][5];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const int col = 32 * m + (lane >> 1), xi = x0 - 4 + col;
-            const bool ok = col < IWX && xi >= 0 && xi < W && !(m == 2 && lane >= 16);
-            const int cc = min(col, IWX - 1), ip = cc - 4;
-            const int sub = wq * 32 + (lane & 1) * 16;
-            roff[m] = (unsigned)(cc < 4 ? K::HALO + cc * PXB + sub : cc >= 68 ? K::HALO + (cc - 64) * PXB + sub
-                                        : (ip >> 3) * 1024 + wq * 256 + (ip & 7) * 32 + (lane & 1) * 16);
-            tdst[m] = (unsigned)((8 * (lane & 1)) * P + SK * (lane & 1) + (ok ? 32 * m + (lane >> 1) : IWX + ((lane >> 1) & 7)));
-        }
-        auto tr_read = [&](u32x4 (&v)[3], int slot) {
+            for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) v[m] = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
-        };
-        auto tr_write1 = [&](const u32x4 (&v)[3], int tb, int m, int e) {
-            u16* d = T + tb * TE + tdst[m];
-            const unsigned wv_ = e < 2 ? v[m].x : e < 4 ? v[m].y : e < 6 ? v[m].z : v[m].w;
-            d[e * P] = (e & 1) ? (u16)(wv_ >> 16) : (u16)wv_;
-        };
-        {
-            f32x4 z = {0, 0, 0, 0};
-            for (int i = lane; i < 2 * TBY / 16; i += 64) { *(f32x4*)((char*)T + i * 16) = z; *(f32x4*)((char*)TY + i * 16) = z; }
-        }
-        // ---- operand reads of one transposed x row: centre segment (8 B) + the two neighbour pixels (2 B each)
-        const u16* rd = T + blk * P + SK * (blk >> 3) + 4 * q;
-        unsigned sidebase = lds_addr(rd);
-        asm volatile("" : "+v"(sidebase));
-        int lofs[5], rofs[5];                                 // (t' = 0, q = 0) has no left pixel, (t' = 4, q = 3) no right one inside the row:
-#pragma unroll                                                // both read a finite in-row value; the y pixels they touch are never used
-        for (int t = 0; t < 5; ++t) { lofs[t] = 16 * t - ((t == 0 && q == 0) ? 0 : 1); rofs[t] = 16 * t + ((t == 4 && q == 3) ? 3 : 4); }
-        // ---- y: column masks (whole 4-px segments: W % 4 == 0), T_y destination, staging [px][ch] for the whole-line store
-        unsigned msk[5];
+                for (int t = 0; t < 5; ++t) acc[sl][t] = biasq;
+            unsigned tdst[3];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) msk[t] = ((unsigned)(x0 - 4 + 16 * t + 4 * q) < (unsigned)W) ? 0xffffffffu : 0u;
-        u16* tyw = TY + blk * P + SK * (blk >> 3) + 4 * q;
-        const unsigned ty_lds = lds_addr(smem + K::OFF_TY);
-        auto o_read = [&](u32x4 (&o)[2], int buf) { tr_row(o, ty_lds, 4, buf & 1); };     // T column = strip pixel + 4
-        auto o_store = [&](const u32x4 (&o)[2], int yo) {
-            const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = (yo >= ylo && yo < yhi) ? 0u : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(o[0], ry, (vst0 + ro) | oob0 | oobr, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(o[1], ry, (vst1 + ro) | oob1 | oobr, 0, 0);
-        };
-
-        // ---- rows.  Iteration p works on x row xr = r_lo - 1 + p (transposed in T[tb]); y row m = p - 2 (image row r_lo + m) is complete
-        // after its ky = 2 contribution and leaves in the same iteration.  p = 0, 1 push garbage through the same path (never stored,
-        // overwritten in T_y before the consumer's first read).
-#pragma unroll
-        for (int i = 0; i < RS; ++i) dma(r_lo - 1 + min(i, NP - 1), i % RS);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (r_lo - 1 >= 0) {
-            u32x4 v[3];
-            tr_read(v, 0);
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) tr_write1(v, 0, m, e);
-        }
-        int p = 0, slot = 0, tb = 0;
-        for (;;) {
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (RS - 2)) : "memory");
-                if (!(FZ_ABL & 64)) __builtin_amdgcn_s_barrier();
-                const int xr = r_lo - 1 + p;
-                const int nslot = slot + 1 == RS ? 0 : slot + 1;
-                s16x4 xc[5], xs[5];
-                unsigned xl[5], xr_[5];
-                u32x4 tv[3], ov[2];
-                unsigned yq[5][2];
-#pragma unroll
-                for (int t = 0; t < 5; ++t) xc[t] = *(const s16x4*)&rd[tb * TE + 16 * t];
-#pragma unroll
-                for (int t = 0; t < 5; ++t) {      // through the opaque base: hipcc otherwise merges them with the centre read into ONE misaligned ds_read_b96
-                    xl[t] = *(lds_u16p)(size_t)(sidebase + (unsigned)(tb * TBY + 2 * lofs[t]));
-                    xr_[t] = *(lds_u16p)(size_t)(sidebase + (unsigned)(tb * TBY + 2 * rofs[t]));
-                }
-                tr_read(tv, nslot);
-                // x row xr + 1 outside the image = a zero row: its chunks are masked (behind the MFMAs that follow, not here: no early wait),
-                // so that the transposing writes below clear the image columns of T[tb ^ 1]
-                const unsigned rmask = (xr + 1 >= 0 && xr + 1 < H) ? 0xffffffffu : 0u;
-                o_read(ov, (p & 1) ^ 1);          // y row m = p - 3 sits in T_y[(p - 1) & 1]
-                __builtin_amdgcn_sched_barrier(0);
-                // 60 MFMAs in the order (tap row ky = 2, 1, 0; operand centre-hi, centre-lo, side-hi, side-lo; tile): an accumulator is
-                // updated every 5th MFMA.  y row slots: ky = 0 starts row m = p (slot u, C = the bias quad), ky = 1 -> (u + 2) % 3,
-                // ky = 2 finishes (u + 1) % 3.
-#pragma unroll
-                for (int k = 0; k < 60; ++k) {
-                    const int ky = 2 - k / 20, ty = (k % 20) / 5, t = k % 5;
-                    const int sl = ky == 0 ? u : ky == 1 ? (u + 2) % 3 : (u + 1) % 3;
-                    if (FZ_ABL & 1) {
-                        asm volatile("" : "+v"(acc[sl][t]) : "v"(xc[t]), "v"(xs[t]), "v"(tch[ky]), "v"(tcl[ky]), "v"(tsh[ky]), "v"(tsl[ky]));
-                    } else if (ky == 0 && ty == 0) {
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[sl][t]) : "v"(tch[ky]), "v"(xc[t]), "v"(biasq));
-                    } else if (ty == 0) {
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tch[ky]), "v"(xc[t]));
-                    } else if (ty == 1) {
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tcl[ky]), "v"(xc[t]));
-                    } else if (ty == 2) {
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tsh[ky]), "v"(xs[t]));
-                    } else {
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tsl[ky]), "v"(xs[t]));
-                    }
-                    // side operand of tile k: {left pixel, right pixel, 0, 0}, made here - ten slots ahead of its first MFMA (10 + t): the asm
-                    // MFMAs get no VALU-write -> MFMA-read wait states from the compiler; the opaque "+v" keeps the pair from being re-made later
-                    if (k < 5) {
-                        xs[k] = __builtin_bit_cast(s16x4, u32x2{xl[k] | (xr_[k] << 16), 0u});
-                        asm volatile("" : "+v"(xs[k]));
-                    }
-                    if (!(FZ_ABL & 16) && k == 2) o_store(ov, r_lo + p - 3);    // y row m = p - 3, written to T_y in the previous iteration
-                    if (k == 4) {
-                        if (!(FZ_ABL & 32)) dma(r_lo - 1 + min(p + RS, NP - 1), slot);    // row p's slot: every producer transposed it before this barrier
-                        tv[0] &= rmask; tv[1] &= rmask; tv[2] &= rmask;
-                    }
-                    if (!(FZ_ABL & 4) && k >= 5 && k < 13) tr_write1(tv, tb ^ 1, 0, k - 5);
-                    if (!(FZ_ABL & 4) && k >= 13 && k < 21) tr_write1(tv, tb ^ 1, 1, k - 13);
-                    if (k >= 23 && k < 28) {
-                        // the finished row's last update was MFMA 15..19: pin its readers behind this position (asm MFMAs get no hazard padding)
-                        const int tt = k - 23, fs = (u + 1) % 3;
-                        asm volatile("" : "+v"(acc[fs][tt]));
-                        yq[tt][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][0], acc[fs][tt][1]}, bf16x2_t)) & msk[tt];
-                        yq[tt][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][2], acc[fs][tt][3]}, bf16x2_t)) & msk[tt];
-                        *(u32x2*)&tyw[(p & 1) * TE + 16 * tt] = u32x2{yq[tt][0], yq[tt][1]};
-                    }
-                    if (!(FZ_ABL & 4) && k >= 28 && k < 36) tr_write1(tv, tb ^ 1, 2, k - 28);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                slot = nslot;
-                tb ^= 1;
-                if (++p >= NP) goto pdone;
+            for (int m = 0; m < 3; ++m) {
+                const int col_ = 32 * m + (lane >> 1), xi = x0 - 4 + col_;
+                const bool ok = col_ < IWX && xi >= 0 && xi < W && !(m == 2 && lane >= 16);
+                tdst[m] = (unsigned)((8 * (lane & 1)) * P + SK * (lane & 1) + (ok ? 32 * m + (lane >> 1) : IWX + ((lane >> 1) & 7)));
             }
-        }
-    pdone:
-        {   // the y row staged by the last iteration (global iteration NP = the consumer's last row)
+            auto tr_write1 = [&](const u32x4 (&v)[3], int tb, int m, int e) {
+                u16* d = T + tb * TE + tdst[m];
+                const unsigned wv_ = e < 2 ? v[m].x : e < 4 ? v[m].y : e < 6 ? v[m].z : v[m].w;
+                d[e * P] = (e & 1) ? (u16)(wv_ >> 16) : (u16)wv_;
+            };
+            {   // columns outside the image are never written: they must read as zeros
+                f32x4 z = {0, 0, 0, 0};
+                for (int i = lane; i < 2 * TBY / 16; i += 64) *(f32x4*)((char*)T + i * 16) = z;
+            }
+            // ---- y: column masks (whole 4-px segments: W % 4 == 0).  Whole strips (W % 64 == 0) can only lose the left halo of tile 0
+            // (strip 0) and the right halo of tile 4 (last strip); MASKALL handles any width
+            unsigned msk[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) msk[t] = ((unsigned)(x0 - 4 + 16 * t + 4 * q) < (unsigned)W) ? 0xffffffffu : 0u;
+            // ---- LDS-DMA of one x row (dw7_mfma_kernel's piece layout: 8 px x 128 B per 1-KiB piece, 16-B chunks stored
+            // [producer wave][px][half] so that a wave's ds_read_b128 of its 32-B column is conflict-free; halo [4 left | 4 right][128 B]);
+            // producer wq issues 2 of the 8 interior pieces and a quarter of the halo.  The producers issue NO stores (the consumers store
+            // y and A): their vmcnt counts exactly these loads, in order
+            const int ipx = x0 + 16 * wq + ((lane >> 1) & 7), ioff = (lane >> 4) * 32 + (lane & 1) * 16;
+            const unsigned vint0 = goff(ipx, ioff), vint1 = goff(ipx + 8, ioff);
+            const int hb = 256 * wq + 16 * (lane & 15), hp = hb / PXB;
+            const unsigned vhalo = goff(hp < 4 ? x0 - 4 + hp : x0 + 60 + hp, hb % PXB);
+            auto dma = [&](int pp, int slot) {                   // x row of iteration min(pp, NP - 1)
+                const char* rb = ximg + (size_t)min(max(r_lo - 1 + min(pp, NP - 1), 0), H - 1) * row_bytes;
+                const unsigned d0 = raw_lds + slot * RAWB + 2048 * wq, dh = raw_lds + slot * RAWB + K::HALO + 256 * wq;
+                unsigned keep; unsigned long long ex;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+                             "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
+                             "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
+                             "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep), "=&s"(ex) : "v"(vint0), "v"(vint1), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb) : "memory", "scc");
+            };
+
+            // ---- rows.  Iteration p works on x row xr = r_lo - 1 + p (transposed in T[tb]; the shared zero image when xr is outside the
+            // picture); y row m = p - 2 (image row r_lo + m) is complete after its ky = 2 contribution and leaves in the same iteration.
+            // p = 0, 1 push garbage through the same path (never stored, overwritten in T_y before the consumer's first read).
+            // x rows of iterations 0 .. RS - 1 up front; then row p + RS during iteration p, into the slot of row p (every producer transposed
+            // it before barrier p).  Own pieces of row p + 1 have landed once at most the RS - 2 later rows' pieces are outstanding.
+#pragma unroll
+            for (int i = 0; i < RS; ++i) dma(i, i % RS);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // prologue barrier
+            {
+                u32x4 v[3];
+                tr_read(v, 0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) tr_write1(v, 0, m, e);
+            }
+            // operands of one transposed x row: centre segments (8 B) and the neighbour pixels (2 B each, through the opaque base: hipcc otherwise
+            // merges them with the centre read into ONE misaligned ds_read_b96).  They are read one iteration AHEAD (T is private to the wave:
+            // no barrier between its transposing writes and these reads), so that the MFMA stream starts right behind the row barrier.
+            s16x4 xc_n[5];
+            unsigned xl_n[5], xr_n[5];
+            auto x_fetch = [&](int xrow, int tbuf) {
+                asm volatile("" ::: "memory");                  // the u16 transposing stores above must stay above these reads
+                const int ib = (xrow >= 0 && xrow < H) ? tbuf * TE : zrel;     // the shared zero image for a row outside the picture
+#pragma unroll
+                for (int t = 0; t < 5; ++t) xc_n[t] = *(const s16x4*)&rd[ib + 16 * t];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    xl_n[t] = *(lds_u16p)(size_t)(sidebase + (unsigned)(2 * (ib + lofs[t])));
+                    xr_n[t] = *(lds_u16p)(size_t)(sidebase + (unsigned)(2 * (ib + rofs[t])));
+                }
+            };
+            x_fetch(r_lo - 1, 0);
+            int p = 0, slot = 0, tb = 0, tyb = 0;                // tyb: T_y image of the row finished in this iteration (rotates over NTY)
+#ifdef FZ_TRACE
+            unsigned long long ts[8] = {};
+#endif
+            for (;;) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    FZ_TS(5);
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (RS - 2)) : "memory");
+                    FZ_TS(6);
+                    if (!(FZ_ABL & 64)) __builtin_amdgcn_s_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    FZ_TS_DUMP(0, p);
+                    FZ_TS(0);
+                    const int xr = r_lo - 1 + p;
+                    const int nslot = slot + 1 == RS ? 0 : slot + 1;
+                    s16x4 xc[5];
+                    unsigned xl[5], xr_[5];
+                    u32x4 tv[3];
+                    unsigned yq[5][2];
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) { xc[t] = xc_n[t]; xl[t] = xl_n[t]; xr_[t] = xr_n[t]; }     // fetched during the previous iteration
+                    __builtin_amdgcn_sched_barrier(0);
+                    // 60 MFMAs in the order (tap row ky = 2, 1, 0; operand centre-hi, centre-lo, side-hi, side-lo; tile): an accumulator is
+                    // updated every 5th MFMA.  y row slots: ky = 0 starts row m = p (slot u, C = the bias quad), ky = 1 -> (u + 2) % 3,
+                    // ky = 2 finishes (u + 1) % 3.
+#pragma unroll
+                    for (int k = 0; k < 60; ++k) {
+                        const int ky = 2 - k / 20, ty = (k % 20) / 5, t = k % 5;
+                        const int sl = ky == 0 ? u : ky == 1 ? (u + 2) % 3 : (u + 1) % 3;
+                        if (FZ_ABL & 1) {
+                            asm volatile("" : "+v"(acc[sl][t]) : "v"(xc[t]), "v"(xs[t]), "v"(tch[ky]), "v"(tcl[ky]), "v"(tsh[ky]), "v"(tsl[ky]));
+                        } else if (ky == 0 && ty == 0) {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[sl][t]) : "v"(tch[ky]), "v"(xc[t]), "v"(biasq));
+                        } else if (ty == 0) {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tch[ky]), "v"(xc[t]));
+                        } else if (ty == 1) {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tcl[ky]), "v"(xc[t]));
+                        } else if (ty == 2) {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tsh[ky]), "v"(xs[t]));
+                        } else {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tsl[ky]), "v"(xs[t]));
+                        }
+                        // side operand of tile k: its low word is made here - ten slots ahead of its first MFMA (10 + t): the asm MFMAs get no
+                        // VALU-write -> MFMA-read wait states from the compiler
+                        if (k < 5) {
+                            u32x2 w2 = __builtin_bit_cast(u32x2, xs[k]);
+                            w2.x = xl[k] | (xr_[k] << 16);
+                            xs[k] = __builtin_bit_cast(s16x4, w2);
+                            asm volatile("" : "+v"(xs[k]));
+                        }
+                        if (k == 1) tr_read(tv, nslot);
+                        if (!(FZ_ABL & 32) && k == 6) dma(p + RS, slot);
+                        if (k == 40) x_fetch(xr + 1, tb ^ 1);      // row p + 1's image is complete (chunk 2 went in at k = 28 .. 35)
+                        if (k == 0) FZ_TS(1);
+                        if (k == 20) FZ_TS(2);
+                        if (k == 40) FZ_TS(3);
+                        if (k == 59) FZ_TS(4);
+                        if (!(FZ_ABL & 4) && k >= 7 && k < 15) tr_write1(tv, tb ^ 1, 0, k - 7);
+                        if (!(FZ_ABL & 4) && k >= 15 && k < 23) tr_write1(tv, tb ^ 1, 1, k - 15);
+                        if (k >= 23 && k < 28) {
+                            // the finished row's last update was MFMA 15..19: pin its readers behind this position (asm MFMAs get no hazard padding)
+                            const int tt = k - 23, fs = (u + 1) % 3;
+                            asm volatile("" : "+v"(acc[fs][tt]));
+                            yq[tt][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][0], acc[fs][tt][1]}, bf16x2_t));
+                            yq[tt][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][2], acc[fs][tt][3]}, bf16x2_t));
+                            if (MASKALL || tt == 0 || tt == 4) { yq[tt][0] &= msk[tt]; yq[tt][1] &= msk[tt]; }
+                            *(u32x2*)&tyw[tyb * TE + 16 * tt] = u32x2{yq[tt][0], yq[tt][1]};
+                        }
+                        if (!(FZ_ABL & 4) && k >= 28 && k < 36) tr_write1(tv, tb ^ 1, 2, k - 28);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    slot = nslot;
+                    tb ^= 1;
+                    tyb = tyb + 1 == K::NTY ? 0 : tyb + 1;
+                    if (++p >= NP) goto pdone;
+                }
+            }
+        pdone:
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            u32x4 ov[2];
-            o_read(ov, (NP & 1) ^ 1);
-            o_store(ov, r_lo + NP - 3);
+            for (int i = 0; i < 3 + ntail; ++i) __builtin_amdgcn_s_barrier();     // global iterations NP, NP + 1 (the consumer's last rows) and the consumer's tail
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // no LDS-DMA in flight when the raw ring is re-used / the LDS released
+            __builtin_amdgcn_s_barrier();                                           // end of the segment: the LDS images may be re-used
         }
-        for (int i = 0; i < 1 + ntail; ++i) __builtin_amdgcn_s_barrier();     // the consumer's tail
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // no LDS-DMA in flight when the LDS is released
     } else {
-        // =========================================================== CONSUMER: T_y -> A (HBM); dw7_mfma_kernel's row loop
+        // =========================================================== CONSUMER: T_y -> A (HBM), y (HBM); dw7_mfma_kernel's row loop
+#ifndef FZ_CPRIO
+#define FZ_CPRIO 0
+#endif
+        // the consumer carries 84 of the 144 MFMAs a SIMD issues per row and is the wave the row barrier waits for: it wins the arbitration
+        if (FZ_CPRIO) __builtin_amdgcn_s_setprio(FZ_CPRIO);
         u16* OA = (u16*)(smem + K::OFF_OA + wq * 2 * TBY);    // this wave's [2][16 ch][P px] A rows (column = strip pixel)
         const unsigned oa_lds = lds_addr(smem + K::OFF_OA);
-        const u16* TY = (const u16*)(smem + K::OFF_TY + wq * 2 * TBY);
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a + (size_t)n * H * W * C), 0, img_bytes, 0x00020000);
+        const u16* TY = (const u16*)(smem + K::OFF_TY + wq * K::NTY * TBY);
+        const unsigned ty_lds = lds_addr(smem + K::OFF_TY);
         s16x4 bop[7][3];
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int sg = 0; sg < 3; ++sg)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int kx = 4 * (s - 1) + k - q + 3;
+                    const int kx = 4 * (sg - 1) + k - q + 3;
                     const float v = (kx >= 0 && kx < 7) ? w7[(size_t)(ky * 7 + kx) * C + c0 + blk] : 0.f;
-                    bop[ky][s][k] = (short)fz_bf16_rne(v);
+                    bop[ky][sg][k] = (short)fz_bf16_rne(v);
                 }
-        const float bv = b7 ? b7[c0 + blk] : 0.f;
-        f32x4 biasq = {bv, bv, bv, bv};
-        asm volatile("" : "+v"(biasq));
-        f32x4 acc[7][NT];
-#pragma unroll
-        for (int sl = 0; sl < 7; ++sl)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[sl][t] = biasq;
+        const float bv7 = b7 ? b7[c0 + blk] : 0.f;
+        f32x4 biasq = {bv7, bv7, bv7, bv7};
+        // operand roles swapped like the producer's (A = Toeplitz^T, B = pixels: the same register contents, the same products): lane 4 b + j
+        // holds pixels 16 t + 4 j .. + 3 of channel b - one 8-byte LDS write per tile
+        u16* oaw = OA + blk * P + SK * (blk >> 3) + 4 * q;
         auto stage_cvt = [&](unsigned (&pk)[2 * NT], f32x4 (&av)[NT]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -336,109 +389,156 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
                 pk[2 * t + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{av[t][2], av[t][3]}, bf16x2_t));
             }
         };
-        // operand roles swapped like the producer's (A = Toeplitz^T, B = pixels: the same register contents, the same products): lane 4 b + j
-        // holds pixels 16 t + 4 j .. + 3 of channel b - one 8-byte LDS write per tile
-        u16* oaw = OA + blk * P + SK * (blk >> 3) + 4 * q;
         auto stage_write1 = [&](const unsigned (&pk)[2 * NT], int ob, int t) {
             *(u32x2*)&oaw[(ob & 1) * TE + 16 * t] = u32x2{pk[2 * t], pk[2 * t + 1]};
         };
-        auto o_read = [&](u32x4 (&o)[2], int ob) { tr_row(o, oa_lds, 0, ob & 1); };
-        auto o_store = [&](const u32x4 (&o)[2], int yo) {
-            const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(o[0], ra, (vst0 + ro) | oob0 | oobr, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(o[1], ra, (vst1 + ro) | oob1 | oobr, 0, 0);
-        };
+        auto o_read = [&](u32x4 (&o)[2], int ob) { tr_row(o, oa_lds, 2, 0, ob & 1); };
+        auto y_read = [&](u32x4 (&o)[2], int buf) { tr_row(o, ty_lds, K::NTY, 4, buf); };     // T column = strip pixel + 4
         const u16* rd = TY + blk * P + SK * (blk >> 3) + 4 * q;
-        __builtin_amdgcn_s_barrier();                          // the producers' prologue barrier
-        __builtin_amdgcn_s_barrier();                          // global iterations 0, 1, 2: y rows 0 is written during iteration 2
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        int r = r_lo, ob = 0, tb = 0;                          // tb: T_y buffer of y row r = (r - r_lo) & 1
-        float amx = 0.f, cand = 0.f;
-        for (;;) {
+
+        while (g0 < g1) {
+            const int col = g0 / H, ylo = g0 - col * H, yhi = min(H, ylo + (g1 - g0));
+            const int n = col / nstrip, strip = col - n * nstrip, x0 = strip * SW;
+            g0 += yhi - ylo;
+            const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3);
+            auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + off); };
+            const int dpx = x0 + dpxr;
+            const unsigned vst0 = goff(dpx, (ds_ & 7) * 16), oob0 = dpx < W ? 0u : 0x80000000u;
+            const unsigned vst1 = goff(dpx + 8, (ds_ & 7) * 16), oob1 = dpx + 8 < W ? 0u : 0x80000000u;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a + (size_t)n * H * W * C), 0, img_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)n * H * W * C), 0, img_bytes, 0x00020000);
+            asm volatile("" : "+v"(biasq));
+            f32x4 acc[7][NT];
 #pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (!(FZ_ABL & 64)) __builtin_amdgcn_s_barrier();
-                s16x4 av[3][NT];
-                u32x4 ov[2];
-                unsigned pk[2 * NT];
+            for (int sl = 0; sl < 7; ++sl)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) av[0][t] = *(const s16x4*)&rd[tb * TE + 16 * t];
-                o_read(ov, ob ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < 84; ++k) {
-                    const int s = k / 28, ky = 6 - (k % 28) / 4, t = k % 4;
-                    if (FZ_ABL & 2)
-                        asm volatile("" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(av[s][t]), "v"(bop[ky][s]));
-                    else if (s == 0 && ky == 0)
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[(u + 6 - ky) % 7][t]) : "v"(bop[ky][s]), "v"(av[s][t]), "v"(biasq));
-                    else
-                        asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(bop[ky][s]), "v"(av[s][t]));
-                    if (k == 2) {
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) av[1][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 4];
-                    }
-                    if (!(FZ_ABL & 16) && k == 5) o_store(ov, r - 4);
-                    if (k == 30) {
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) av[2][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 8];
-                    }
-                    if (k == 62) {
-                        asm volatile("" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
-                        stage_cvt(pk, acc[u]);
-                    }
-                    if (!(FZ_ABL & 8) && k >= 64 && k < 68) stage_write1(pk, ob, k - 64);
-                    if (AMAX && k == 63) cand = 0.f;
-                    if (AMAX && (k == 63 || (k >= 80 && k < 83))) {
-                        const int t2 = k == 63 ? 0 : k - 79;
-                        cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t2][0])), __builtin_fabsf(acc[u][t2][1]));
-                        cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t2][2])), __builtin_fabsf(acc[u][t2][3]));
-                    }
-                    if (AMAX && k == 83) amx = (r - 3 >= ylo) ? __builtin_fmaxf(amx, cand) : amx;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                ob ^= 1;
-                tb ^= 1;
-                if (++r >= r_hi) goto cdone;
-            }
-        }
-    cdone:
-        {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int t = 0; t < NT; ++t) acc[sl][t] = biasq;
+            auto o_store = [&](const u32x4 (&o)[2], int yo) {
+                const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(o[0], ra, (vst0 + ro) | oob0 | oobr, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o[1], ra, (vst1 + ro) | oob1 | oobr, 0, 0);
+            };
+            auto y_store = [&](const u32x4 (&o)[2], int yo) {      // the RepMixer output row the 7x7 is reading: stored by its own chunk only
+                const unsigned ro = (unsigned)yo * row_bytes, oobr = (yo >= ylo && yo < yhi) ? 0u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(o[0], ry, (vst0 + ro) | oob0 | oobr, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o[1], ry, (vst1 + ro) | oob1 | oobr, 0, 0);
+            };
+            __builtin_amdgcn_s_barrier();                          // the producers' prologue barrier
+            __builtin_amdgcn_s_barrier();                          // global iterations 0 .. 3: y row 0 is written during iteration 2 (image 2 % NTY),
+            __builtin_amdgcn_s_barrier();                          // its first operands are fetched behind barrier 3, one iteration ahead of their
+            __builtin_amdgcn_s_barrier();                          // MFMAs - the consumer's stream starts right behind the row barrier too
             __builtin_amdgcn_s_barrier();
-            u32x4 ov[2];
-            o_read(ov, ob ^ 1);
-            o_store(ov, r_hi - 4);
-        }
-        for (int yo = max(ylo, r_hi - 3); yo < yhi; ++yo) {     // rows whose last input row lies below the image (ntail of them)
-            const int sl = (yo - r_lo + 3) % 7;
+            s16x4 av0_n[NT];
 #pragma unroll
-            for (int s7 = 0; s7 < 7; ++s7)
-                if (s7 == sl) {
+            for (int t = 0; t < NT; ++t) av0_n[t] = *(const s16x4*)&rd[(2 % K::NTY) * TE + 16 * t];
+            int r = r_lo, ob = 0, tb = 2 % K::NTY;                 // tb: T_y image of y row r = (r - r_lo + 2) % NTY
+            float cand = 0.f;
+#ifdef FZ_TRACE
+            unsigned long long ts[8] = {};
+#endif
+            for (;;) {
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    FZ_TS(5);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    FZ_TS(6);
+                    if (!(FZ_ABL & 64)) __builtin_amdgcn_s_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    FZ_TS_DUMP(1, r - r_lo + 4);
+                    FZ_TS(0);
+                    s16x4 av[3][NT];
+                    u32x4 ov[2], yv[2];
                     unsigned pk[2 * NT];
-                    stage_cvt(pk, acc[s7]);
+                    const int tbn = tb + 1 == K::NTY ? 0 : tb + 1;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) stage_write1(pk, ob, j);
-                    if constexpr (AMAX) {
+                    for (int t = 0; t < NT; ++t) av[0][t] = av0_n[t];          // fetched during the previous iteration
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
+                    for (int k = 0; k < 84; ++k) {
+                        const int s = k / 28, ky = 6 - (k % 28) / 4, t = k % 4;
+                        if (FZ_ABL & 2)
+                            asm volatile("" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(av[s][t]), "v"(bop[ky][s]));
+                        else if (s == 0 && ky == 0)
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[(u + 6 - ky) % 7][t]) : "v"(bop[ky][s]), "v"(av[s][t]), "v"(biasq));
+                        else
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[(u + 6 - ky) % 7][t]) : "v"(bop[ky][s]), "v"(av[s][t]));
+                        if (k == 1) o_read(ov, ob ^ 1);
+                        if (k == 2) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) amx = __builtin_fmaxf(amx, __builtin_fabsf(acc[s7][t][i]));
+                            for (int tt = 0; tt < NT; ++tt) av[1][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 4];
+                        }
+                        if (k == 3) y_read(yv, tb);
+                        if (k == 70) {                               // the next row's first operands (written by the producer one iteration ago)
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) av0_n[tt] = *(const s16x4*)&rd[tbn * TE + 16 * tt];
+                        }
+                        if (!(FZ_ABL & 16) && k == 10) o_store(ov, r - 4);
+                        if (!(FZ_ABL & 16) && k == 18) y_store(yv, r);
+                        if (k == 0) FZ_TS(1);
+                        if (k == 28) FZ_TS(2);
+                        if (k == 56) FZ_TS(3);
+                        if (k == 83) FZ_TS(4);
+                        if (k == 30) {
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) av[2][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 8];
+                        }
+                        if (k == 62) {
+                            asm volatile("" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
+                            stage_cvt(pk, acc[u]);
+                        }
+                        if (!(FZ_ABL & 8) && k >= 64 && k < 68) stage_write1(pk, ob, k - 64);
+                        if (AMAX && k == 63) cand = 0.f;
+                        if (AMAX && (k == 63 || (k >= 80 && k < 83))) {
+                            const int t2 = k == 63 ? 0 : k - 79;
+                            cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t2][0])), __builtin_fabsf(acc[u][t2][1]));
+                            cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t2][2])), __builtin_fabsf(acc[u][t2][3]));
+                        }
+                        if (AMAX && k == 83) amx = (r - 3 >= ylo) ? __builtin_fmaxf(amx, cand) : amx;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    ob ^= 1;
+                    tb = tbn;
+                    if (++r >= r_hi) goto cdone;
                 }
+            }
+        cdone:
+            {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                u32x4 ov[2];
+                o_read(ov, ob ^ 1);
+                o_store(ov, r_hi - 4);
+            }
+            for (int yo = max(ylo, r_hi - 3); yo < yhi; ++yo) {     // rows whose last input row lies below the image (ntail of them)
+                const int sl = (yo - r_lo + 3) % 7;
+#pragma unroll
+                for (int s7 = 0; s7 < 7; ++s7)
+                    if (s7 == sl) {
+                        unsigned pk[2 * NT];
+                        stage_cvt(pk, acc[s7]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) stage_write1(pk, ob, j);
+                        if constexpr (AMAX) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) amx = __builtin_fmaxf(amx, __builtin_fabsf(acc[s7][t][i]));
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                u32x4 ov[2];
+                o_read(ov, ob);
+                o_store(ov, yo);
+                ob ^= 1;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            u32x4 ov[2];
-            o_read(ov, ob);
-            o_store(ov, yo);
-            ob ^= 1;
+            __builtin_amdgcn_s_barrier();                                   // end of the segment
         }
         if constexpr (AMAX) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
-            if (lane == 0) ((float*)(smem + K::OFF_TX))[wq] = amx;       // the producers' images are dead (their loops ended before the tail barriers)
+            if (lane == 0) ((float*)(smem + K::OFF_TX))[wq] = amx;       // the producers' images are dead (end-of-segment barrier)
         }
     }
     if constexpr (AMAX) {                                      // workgroup maximum -> one atomic per workgroup, slot by block id
@@ -453,30 +553,67 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
 
 }  // namespace
 
-// Rows per chunk: 32 output rows (40 x rows, 38 y rows per 32) while the launch still gives every CU a workgroup, 16 below that; 0 = the
-// launch is too small for a serial march of one workgroup per CU (the two-kernel route has finer tiles).
-static int fz_rows_per_chunk(int B, int H, int W, int C)
+// Output rows per workgroup: the columns' rows are dealt out evenly over one workgroup per CU (the kernel needs 102 KB of LDS: one
+// resident workgroup per CU), but never fewer than 16 per workgroup (every segment costs 8 halo rows and a prologue).
+static int fz_cu_count()
 {
-    const long long per_row_chunk = (long long)B * (C / 64) * ((W + 63) / 64);
-    if (per_row_chunk * ((H + 31) / 32) >= 224) return 32;
-    if (per_row_chunk * ((H + 15) / 16) >= 224) return 16;
-    return 0;
-}
-
-// 1 = this kernel takes the shape; force: ignore the launch-size rule (tests)
-extern "C" int fvhd_dw3_dw7_supported(int B, int H, int W, int C, int force)
-{
-    if (!(C % 64 == 0 && W % 4 == 0 && W >= 16 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
-    if (force) return 1;
-    return W >= 32 && fz_rows_per_chunk(B, H, W, C) > 0;
+    static int n[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!n[dev & 63]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev & 63] = v;
+    }
+    return n[dev & 63];
 }
 
 #ifdef FVHD_DEBUG_KNOBS
-static int g_fz_rc = 0;
+static int g_fz_rc = 0;                                       // > 0: output rows per workgroup forced (tools/bench_ops.py dw37)
 extern "C" void fvhd_debug_set_fz_rc(int rc) { g_fz_rc = rc; }
 #else
 static constexpr int g_fz_rc = 0;
 #endif
+
+static int fz_rows_per_wg(long long total_rows, int ncb)       // total_rows: of ONE channel block; ncb workgroups work on every run of rows
+{
+    if (g_fz_rc > 0) return g_fz_rc;
+    const int groups = fz_cu_count() / ncb > 0 ? fz_cu_count() / ncb : 1;
+    const long long per_group = (total_rows + groups - 1) / groups;
+    return (int)(per_group < 16 ? 16 : per_group);
+}
+
+// 1 = this kernel takes the shape; force: ignore the launch-size rule (tests).  By itself the tower takes it from 32 output rows per CU
+// on (B = 32 at 1024^2: 96 rows at C = 192, 48 at C = 384): below that the halo rows and the serial march of one workgroup per CU lose to the
+// finer tiles of the two-kernel route.
+extern "C" int fvhd_dw3_dw7_supported(int B, int H, int W, int C, int force)
+{
+    if (!(C % 64 == 0 && W % 4 == 0 && W >= 16 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
+    if (force) return 1;
+    const long long total = (long long)B * (C / 64) * ((W + 63) / 64) * H;       // output rows x channel blocks: 32 per CU
+    return W >= 32 && total >= 32ll * fz_cu_count();
+}
+
+template <bool AMAX, bool MASKALL>
+static int fz_launch(hipStream_t st, const void* x, void* y, void* a, const float* w3, const float* b3, const float* w7, const float* b7,
+                     int B, int H, int W, int C, unsigned* amax)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute((const void*)dw3_dw7_kernel<AMAX, MASKALL>, hipFuncAttributeMaxDynamicSharedMemorySize, FzCfg::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev & 63] = true;
+    }
+    const int nstrip = (W + 63) / 64, ncb = C / 64;
+    const long long total = (long long)B * nstrip * H;                   // output rows of one channel block
+    if (total <= 0 || total > 0x7fffffffll) return (int)hipErrorInvalidValue;
+    const int rpw = fz_rows_per_wg(total, ncb);
+    const long long grid = ((total + rpw - 1) / rpw) * ncb;
+    dw3_dw7_kernel<AMAX, MASKALL><<<(int)grid, 512, FzCfg::LDS, st>>>((const u16*)x, (u16*)y, (u16*)a, w3, b3, w7, b7, H, W, C, nstrip, rpw, (int)total, amax);
+    return (int)hipGetLastError();
+}
 
 // x, y, a [B, H, W, C] bf16 (NHWC); w3 fp32 [9][C], b3 fp32 [C] or null; w7 fp32 [49][C] (BatchNorm folded), b7 fp32 [C] or null;
 // amax: null or FVHD_AMAX_SLOTS words receiving max |A| (fp32 bit patterns)
@@ -484,22 +621,14 @@ extern "C" int fvhd_launch_dw3_dw7(hipStream_t st, const void* x, void* y, void*
                                    const float* b7, int B, int H, int W, int C, unsigned* amax)
 {
     if (!fvhd_dw3_dw7_supported(B, H, W, C, 1)) return (int)hipErrorInvalidValue;
-    static bool attr_set[64][2] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 63][amax ? 1 : 0]) {
-        hipError_t e = amax ? hipFuncSetAttribute((const void*)dw3_dw7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FzCfg::LDS)
-                            : hipFuncSetAttribute((const void*)dw3_dw7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FzCfg::LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set[dev & 63][amax ? 1 : 0] = true;
-    }
-    const int rc_ = g_fz_rc > 0 ? g_fz_rc : fz_rows_per_chunk(B, H, W, C), RC = rc_ > 0 ? rc_ : 16;
-    const int nstrip = (W + 63) / 64, nchunk = (H + RC - 1) / RC;
-    const long long grid = (long long)B * (C / 64) * nstrip * nchunk;
-    if (grid <= 0 || grid > 0x7fffffffll) return (int)hipErrorInvalidValue;
-    if (amax)
-        dw3_dw7_kernel<true><<<(int)grid, 512, FzCfg::LDS, st>>>((const u16*)x, (u16*)y, (u16*)a, w3, b3, w7, b7, H, W, C, RC, nstrip, nchunk, amax);
-    else
-        dw3_dw7_kernel<false><<<(int)grid, 512, FzCfg::LDS, st>>>((const u16*)x, (u16*)y, (u16*)a, w3, b3, w7, b7, H, W, C, RC, nstrip, nchunk, nullptr);
-    return (int)hipGetLastError();
+    const bool maskall = W % 64 != 0;
+    if (amax) return maskall ? fz_launch<true, true>(st, x, y, a, w3, b3, w7, b7, B, H, W, C, amax) : fz_launch<true, false>(st, x, y, a, w3, b3, w7, b7, B, H, W, C, amax);
+    return maskall ? fz_launch<false, true>(st, x, y, a, w3, b3, w7, b7, B, H, W, C, nullptr) : fz_launch<false, false>(st, x, y, a, w3, b3, w7, b7, B, H, W, C, nullptr);
 }
+
+#ifdef FZ_TRACE
+extern "C" int fvhd_debug_fz_trace(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_trace_buf), sizeof(unsigned long long) * (n < 512 ? n : 512));
+}
+#endif

@@ -145,8 +145,8 @@ struct GuardSlot { unsigned* host = nullptr; hipEvent_t ev = nullptr; bool pendi
 struct GuardHit { int step; float amax; };
 
 const char* kClassNames[] = {"stem", "dw3", "dw7", "dw_down", "gemm_fc1", "gemm_fc2", "gemm_1x1", "gemm_qkv",
-                             "gemm_proj", "layernorm", "attention", "head", "projector", "ffn_fused"};
-enum { C_STEM, C_DW3, C_DW7, C_DWDOWN, C_FC1, C_FC2, C_1X1, C_QKV, C_PROJ, C_LN, C_ATT, C_HEAD, C_PROJECTOR, C_FFN, C_COUNT };
+                             "gemm_proj", "layernorm", "attention", "head", "projector", "ffn_fused", "dw_mix"};
+enum { C_STEM, C_DW3, C_DW7, C_DWDOWN, C_FC1, C_FC2, C_1X1, C_QKV, C_PROJ, C_LN, C_ATT, C_HEAD, C_PROJECTOR, C_FFN, C_DWMIX, C_COUNT };
 
 }  // namespace
 
@@ -170,6 +170,7 @@ struct fvhd_ctx {
     bool ws_captured = false;
     std::vector<char*> ws_retired;
     bool use_fused_ffn = true;   // FVHD_FUSED_FFN=0 falls back to fc1 / fc2 as two GEMM launches (A/B measurements)
+    bool use_fused_dw = true;    // FVHD_FUSED_DW=0: RepMixer dw3x3 and ConvFFN dw7x7 always as two launches (A/B measurements)
     bool use_splitk = true;      // FVHD_GEMM_SPLITK=0: never split the K of the residual GEMMs (A/B measurements)
     // FVHD_FUSED_STEM: 2 (default) the whole convolutional_stem in ONE launch; 1: stem[0] + stem[1] fused, stem[2] as a GEMM launch (rounds
     // 1-3); 0: three launches through a [B,R/2,R/2,96] HBM tensor.  All three give the same bits.
@@ -591,14 +592,22 @@ int run_gemm(fvhd_ctx* c, hipStream_t st, int cls, const char* wbase, const Gemm
 constexpr int kFusedFfnMinRows = 24576;
 
 // ConvFFN + layer scale + residual, in place on x (mci.py:1106-1109 / 1185-1188 second line)
-int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, int B, int H, int Wd, int C, int step)
+bool ffn_takes_fused(const fvhd_ctx* c, const FfnW& f, int M) { return f.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows); }
+
+// range guard, site 0: the depthwise conv that feeds a half-precision fused block also reduces max |A| into this step's slot
+unsigned* ffn_amax_slot(fvhd_ctx* c, const FfnW& f, int M, int step)
+{
+    return (c->guard_active && c->guard_site == 0 && ffn_takes_fused(c, f, M) && f.precision == FVHD_FFN_HALF && step < c->guard_n)
+               ? c->guard_dev + (size_t)step * kAmaxSlots : nullptr;
+}
+
+// have_a: w.A already holds dw7x7(x) + BN (the RepMixerBlock's one-launch dw3x3 -> dw7x7, run_step)
+int run_ffn(fvhd_ctx* c, hipStream_t st, const FfnW& f, const Ws& w, char* x, int B, int H, int Wd, int C, int step, bool have_a = false)
 {
     const int M = B * H * Wd;
     int e;
-    const bool take_fused = f.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows);
-    // range guard: the depthwise conv that feeds a half-precision fused block also reduces max |A| into this step's slot
-    unsigned* amax = (c->guard_active && c->guard_site == 0 && take_fused && f.precision == FVHD_FFN_HALF && step < c->guard_n) ? c->guard_dev + (size_t)step * kAmaxSlots : nullptr;
-    if ((e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0, amax))) return e;
+    const bool take_fused = ffn_takes_fused(c, f, M);
+    if (!have_a && (e = run_dw(c, st, C_DW7, f.dw7, x, w.A, B, H, Wd, C, 1, 1, 0, ffn_amax_slot(c, f, M, step)))) return e;
     if (c->audit_dev) {          // range audit: fc1 + bias as a plain GEMM into the hidden buffer, max |.| of it into this step's slot
         if ((e = run_gemm(c, st, C_FC1, c->wdev, f.fc1, w.A, nullptr, nullptr, w.H, M, FVHD_EPI_BIAS))) return e;
         const long n8 = (long)M * 4 * C / 8;
@@ -662,6 +671,20 @@ int run_step(fvhd_ctx* c, hipStream_t st, const Step& sp, const Ws& w, char*& X,
         // range guard, site 1: the RepMixer's own output y is what the block's dw7x7 reads - max |y| into this step's slot
         const bool fused_half = blk.ffn.fused && c->use_fused_ffn && (c->batch_invariant || M >= kFusedFfnMinRows) && blk.ffn.precision == FVHD_FFN_HALF;
         unsigned* amax = (c->guard_active && c->guard_site == 1 && fused_half && step < c->guard_n) ? c->guard_dev + (size_t)step * kAmaxSlots : nullptr;
+        // RepMixer dw3x3 and the ConvFFN's dw7x7 (+ BN) in ONE launch (round 6, csrc/dwconv_fused.hip: y crosses HBM once) wherever that kernel
+        // takes the shape and the launch fills the chip; never in batch-invariant mode (its y may differ by one bf16 ulp from the VALU kernel's,
+        // and the choice depends on the batch), never with the guard's maximum taken at site 1 (max |y|: that kernel only reduces max |A|)
+        if (c->use_fused_dw && !c->batch_invariant && blk.mixer.K == 3 && blk.ffn.dw7.K == 7 && !(c->guard_active && c->guard_site == 1) &&
+            fvhd_dw3_dw7_supported(B, H, H, C, 0)) {
+            {
+                Scope s(c, st, C_DWMIX);
+                CHECK_LAUNCH(fvhd_launch_dw3_dw7(st, X, T, w.A, c->wp<float>(blk.mixer.w), c->wp<float>(blk.mixer.b), c->wp<float>(blk.ffn.dw7.w),
+                                                 c->wp<float>(blk.ffn.dw7.b), B, H, H, C, ffn_amax_slot(c, blk.ffn, M, step)),
+                             "dw3x3 -> dw7x7 launch");
+            }
+            std::swap(X, T);
+            return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, step, true);
+        }
         if ((e = run_dw(c, st, C_DW3, blk.mixer, X, T, B, H, H, C, 1, 1, 0, amax))) return e;
         std::swap(X, T);
         return run_ffn(c, st, blk.ffn, w, X, B, H, H, C, step);
@@ -848,6 +871,7 @@ int fvhd_create(fvhd_ctx** out, int device, int image_size, int max_batch)
     c->R = image_size;
     c->max_batch = max_batch;
     if (const char* ev = getenv("FVHD_FUSED_FFN")) c->use_fused_ffn = atoi(ev) != 0;
+    if (const char* ev = getenv("FVHD_FUSED_DW")) c->use_fused_dw = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_GEMM_SPLITK")) c->use_splitk = atoi(ev) != 0;
     if (const char* ev = getenv("FVHD_FUSED_STEM")) c->use_fused_stem = atoi(ev);
     if (const char* ev = getenv("FVHD_ATTN_FP8")) c->attn_fp8 = atoi(ev) != 0;

@@ -303,7 +303,7 @@ def bench_gemmsmall():
 
 def bench_dw37(B=32):
     """RepMixer dw3x3 -> ConvFFN dw7x7: the two-kernel route against the fused launch (csrc/dwconv_fused.hip), interleaved rounds on one box;
-    with the debug library also a sweep of the fused kernel's rows per chunk (fvhd_debug_set_fz_rc)"""
+    with the debug library also a sweep of the fused kernel's output rows per workgroup (fvhd_debug_set_fz_rc)"""
     raw = C.CDLL(_lib.LIB_PATH)
     shapes = [(Cc, H) for Cc, H in ((192, 128), (384, 64), (64, 256)) if lib.fvhd_dw3_dw7_supported(B, H, H, Cc, 1)]
     for Cc, H in shapes:
@@ -321,9 +321,9 @@ def bench_dw37(B=32):
         print(f"dw3+dw7 C={Cc:4d} {H}x{H} B={B}: two launches {t2*1e6:7.1f} us ({4*by/t2/1e12:.2f} TB/s of 4 passes)   fused {t1*1e6:7.1f} us "
               f"({3*by/t1/1e12:.2f} TB/s of 3 passes)   rounds {[(round(r[0]*1e6, 1), round(r[1]*1e6, 1)) for r in rounds]}")
         if hasattr(raw, "fvhd_debug_set_fz_rc"):
-            for rc in (16, 22, 32, 43, 64):
+            for rc in (16, 24, 32, 48, 64, 96, 128):
                 raw.fvhd_debug_set_fz_rc(rc)
-                print(f"    rows per chunk {rc:3d}: {timeit(one, iters=30)*1e6:7.1f} us")
+                print(f"    output rows per workgroup {rc:3d}: {timeit(one, iters=30)*1e6:7.1f} us")
             raw.fvhd_debug_set_fz_rc(0)
 
 

@@ -106,6 +106,15 @@ r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs 
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
     FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37_rc.log
     ;;
+r6b)        # round 6: the fused depthwise launch inside the tower: step / tower / precision tests, then FVHD_FUSED_DW=0 / 1 on one box
+    timeout 1200 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tower.py tests/test_gpu_ffn_precision.py tests/test_gpu_ops.py -m gpu -q --maxfail=15 --durations=5 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-300
+    for v in 0 1 0 1; do
+        FVHD_FUSED_DW=$v timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_dw$v.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_dw$v.json")); print("FVHD_FUSED_DW=$v", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw") or k in ("ffn_fused", "stem")}, d["conv_stage"]["frac"])
+PY
+    done
+    ;;
 r5a)        # round 5, first call: whole GPU suite (all failures, not -x), the driver's line, GEMM layout A/B (bits + time), WRITE_SIZE of the GEMM classes
     timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --durations=8 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -30 ${O}_pytest.log | cut -c1-300
     timeout 900 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"; cut -c1-400 ${O}_bench.json; tail -3 ${O}_bench.err

@@ -28,7 +28,7 @@ CLASSES = [  # (class, regex on kernel name); first match wins
     ("dw7_mfma_c96 (C = 96)", r"dw7_mfma_kernelILi6E|dw7_mfma_kernel<6"),
     ("dw7_s1", r"dwconv_tiled_kernelILi7ELi1ELi1E|dwconv_tiled_kernel<7, 1, 1"),
     ("dw3_s1", r"dwconv_tiled_kernelILi3ELi1ELi1E|dwconv_tiled_kernel<3, 1, 1"),
-    ("dw_mixer_fused", r"dwmix_kernel"),
+    ("dw_mixer_fused", r"dw3_dw7_kernel"),
     ("dw_down", r"dwconv_tiled_kernelILi7ELi2ELi2E|dwconv_tiled_kernel<7, 2, 2"),
     ("dw_head", r"dwconv_tiled_kernelILi3ELi1ELi2E|dwconv_tiled_kernel<3, 1, 2"),
     ("stem", r"stem_(fused|conv)_kernel|dwconv_tiled_kernelILi3ELi2ELi1E"),
