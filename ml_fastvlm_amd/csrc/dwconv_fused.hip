@@ -57,8 +57,15 @@ struct FzCfg {
     // raw x rows | transposed x (private per producer wave, 2 each) | y rows (producer -> consumer AND -> the y store, 2 per wave pair) |
     // A rows (consumer -> the A store, 2 per consumer wave): all three images have ONE layout, [wave][buffer][16 ch][P px]
     static constexpr int NTY = 3;                                        // y rows in flight per wave pair: written in iteration g, operands prefetched in g + 1, consumed in g + 2
-    static constexpr int OFF_TX = FZ_RS * RAWB, OFF_TY = OFF_TX + 8 * TB, OFF_OA = OFF_TY + 4 * NTY * TB;
-    static constexpr int OFF_Z = OFF_OA + 8 * TB;                       // one all-zero image: the operand image of an x row outside the picture
+    // The y and A images are also read by the transposing stores: a 32-lane half of a ds_read_b64_tr_b16 addresses rows {0..3, 8..11} (or
+    // {4..7, 12..15}) of all FOUR waves' images at one column.  With rows 8..15 skewed by 128 B the eight rows of one image start on the
+    // eight multiples of 8 dwords (mod 64 banks), and a wave-image stride of 8 bytes more than a multiple of 32 puts the four images on
+    // the four even residues in between: conflict-free (the 64-B skew of the x images and plain strides: 4-way).  The 8-byte writes and the
+    // operand reads of one wave see one image: unchanged, conflict-free.
+    static constexpr int SKO = 64, TBO = (16 * FZ_P + SKO) * 2;          // one y / A image (bytes)
+    static constexpr int WSY = NTY * TBO + 8, WSA = 2 * TBO + 8;         // wave-image strides of the y and the A region
+    static constexpr int OFF_TX = FZ_RS * RAWB, OFF_TY = OFF_TX + 8 * TB, OFF_OA = OFF_TY + 4 * WSY;
+    static constexpr int OFF_Z = (OFF_OA + 4 * WSA + 15) / 16 * 16;     // one all-zero image: the operand image of an x row outside the picture
     static constexpr int LDS = OFF_Z + TB;
 };
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
@@ -66,11 +73,11 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
 // -DFZ_TRACE: cycle stamps (s_memtime) of a few row iterations of one producer and one consumer wave into a device array that
 // fvhd_debug_fz_trace copies out - a timing aid (the SMEM returns share lgkmcnt with the LDS reads: results of a trace build are not to be trusted)
 #ifdef FZ_TRACE
-__device__ unsigned long long fz_trace_buf[2 * 2 * 16 * 8];
+__device__ unsigned long long fz_trace_buf[2 * 4 * 16 * 8];
 #define FZ_TS(i) asm volatile("s_memtime %0" : "=s"(ts[i]))
 #define FZ_TS_DUMP(role, it)                                                                                       \
-    if ((blockIdx.x == 0 || blockIdx.x == 77) && wq == 1 && (it) >= 9 && (it) < 25 && lane == 0) {                  \
-        unsigned long long* d = fz_trace_buf + ((((blockIdx.x == 77) * 2 + (role)) * 16 + ((it) - 9)) * 8);        \
+    if (blockIdx.x == 7 && (it) >= 9 && (it) < 25 && lane == 0) {                                                  \
+        unsigned long long* d = fz_trace_buf + ((((role) * 4 + wq) * 16 + ((it) - 9)) * 8);                        \
         for (int i_ = 0; i_ < 8; ++i_) d[i_] = ts[i_];                                                            \
     }
 #else
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
     // and written by neighbouring CUs at about the same time (DRAM pages), and with one resident workgroup per CU every CU gets the same
     // number of rows whatever B * strips is (B = 32 at C = 384: 32 columns of 64 rows over 42 groups of 6 = 49 rows each).
     using K = FzCfg;
-    constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = FZ_RS, P = FZ_P, RAWB = K::RAWB, TBY = K::TB, TE = TBY / 2, SK = FZ_SK;
+    constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = FZ_RS, P = FZ_P, RAWB = K::RAWB, TBY = K::TB, TE = TBY / 2, SK = FZ_SK, SKO = K::SKO,
+                  TEO = K::TBO / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wq = wv & 3;                                   // channel group of this wave (producer wq and consumer wq + 4 share it)
@@ -109,10 +117,10 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
     // pixel quad 16 wq + 8 h + 4 ((4 g + c) >> 3); output role of lane (g, c = (lane >> 2) & 3, e = lane & 3): channels 8 o .. 8 o + 7
     // (two reads, hf = 0, 1) of pixel 16 wq + 8 h + 4 ((4 g + c) >> 3) + e - so one store instruction (h = 0, 1) moves 8 whole 128-B lines.
     const int ss = 4 * (lane >> 4) + (lane & 3), so = ss & 7, sj = (lane >> 2) & 3, sr = 8 * (so & 1) + sj;    // source: row inside wave (so >> 1)'s image, hf = 0
-    const unsigned trsrc = (unsigned)((sr * P + SK * (sr >> 3) + 16 * wq + 4 * (ss >> 3)) * 2);   // bytes; + wave image (so >> 1), + column offset, + 8 h px, + 4 P hf, + buffer
+    const unsigned trsrc = (unsigned)((sr * P + SKO * (sr >> 3) + 16 * wq + 4 * (ss >> 3)) * 2);   // bytes; + wave image (so >> 1), + column offset, + 8 h px, + 4 P hf, + buffer
     const int ds_ = 4 * (lane >> 4) + ((lane >> 2) & 3), dpxr = 16 * wq + 4 * (ds_ >> 3) + (lane & 3);         // output role: strip pixel (h = 0), 16-B chunk ds_ & 7
-    auto tr_row = [&](u32x4 (&o)[2], unsigned region_lds, int nbuf, int coloff, int buf) {       // the 2 x 2 transposing reads of this wave's 16 pixels
-        const unsigned a0 = region_lds + trsrc + (unsigned)(((so >> 1) * nbuf * TE + coloff + buf * TE) * 2);
+    auto tr_row = [&](u32x4 (&o)[2], unsigned region_lds, int wave_stride, int coloff, int buf) {       // the 2 x 2 transposing reads of this wave's 16 pixels
+        const unsigned a0 = region_lds + trsrc + (unsigned)((so >> 1) * wave_stride + (coloff + buf * TEO) * 2);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(size_t)(a0 + 16 * h));
@@ -126,14 +134,13 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
     if (wv < 4) {
         // =========================================================== PRODUCER: x -> y (HBM) and y -> T_y (LDS)
         u16* T = (u16*)(smem + K::OFF_TX + wq * 2 * TBY);    // private: [2][16 ch][P px] transposed x rows
-        u16* TY = (u16*)(smem + K::OFF_TY + wq * K::NTY * TBY);   // shared with consumer wq + 4: [NTY][16 ch][P px] y rows
+        u16* TY = (u16*)(smem + K::OFF_TY + wq * K::WSY);   // shared with consumer wq + 4: [NTY][16 ch][P px] y rows
         constexpr int ZREL = 0;                              // (placeholder: the zero image's offset is wave dependent, below)
         (void)ZREL;
         const int zrel = (K::OFF_Z - (K::OFF_TX + wq * 2 * TBY)) / 2;      // u16 index of the shared all-zero image relative to T
         {
             f32x4 z = {0, 0, 0, 0};
             for (int i = lane; i < TBY / 16; i += 64) *(f32x4*)(smem + K::OFF_Z + i * 16) = z;       // every producer writes the same zeros
-            for (int i = lane; i < K::NTY * TBY / 16; i += 64) *(f32x4*)((char*)TY + i * 16) = z;
         }
         // ---- transposition raw row -> T (this lane's three 16-B chunks: T column 32 m + lane / 2, channel half lane & 1)
         unsigned roff[3];
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
         int lofs[5], rofs[5];                                 // (t' = 0, q = 0) has no left pixel, (t' = 4, q = 3) no right one inside the row:
 #pragma unroll                                                // both read a finite in-row value; the y pixels they touch are never used
         for (int t = 0; t < 5; ++t) { lofs[t] = 16 * t - ((t == 0 && q == 0) ? 0 : 1); rofs[t] = 16 * t + ((t == 4 && q == 3) ? 3 : 4); }
-        u16* tyw = TY + blk * P + SK * (blk >> 3) + 4 * q;
+        u16* tyw = TY + blk * P + SKO * (blk >> 3) + 4 * q;
         const unsigned raw_lds = lds_addr(raw);
         // ---- Toeplitz^T operands of this lane (channel blk, output pixel i = q of a segment), hi + lo halves of every tap:
         //   centre  [k] = tap(ky, kx = k - q + 1)                     (input pixel k of the SAME segment)
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
                             yq[tt][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][0], acc[fs][tt][1]}, bf16x2_t));
                             yq[tt][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][2], acc[fs][tt][3]}, bf16x2_t));
                             if (MASKALL || tt == 0 || tt == 4) { yq[tt][0] &= msk[tt]; yq[tt][1] &= msk[tt]; }
-                            *(u32x2*)&tyw[tyb * TE + 16 * tt] = u32x2{yq[tt][0], yq[tt][1]};
+                            *(u32x2*)&tyw[tyb * TEO + 16 * tt] = u32x2{yq[tt][0], yq[tt][1]};
                         }
                         if (!(FZ_ABL & 4) && k >= 28 && k < 36) tr_write1(tv, tb ^ 1, 2, k - 28);
                         __builtin_amdgcn_sched_barrier(0);
@@ -362,9 +369,9 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
 #endif
         // the consumer carries 84 of the 144 MFMAs a SIMD issues per row and is the wave the row barrier waits for: it wins the arbitration
         if (FZ_CPRIO) __builtin_amdgcn_s_setprio(FZ_CPRIO);
-        u16* OA = (u16*)(smem + K::OFF_OA + wq * 2 * TBY);    // this wave's [2][16 ch][P px] A rows (column = strip pixel)
+        u16* OA = (u16*)(smem + K::OFF_OA + wq * K::WSA);    // this wave's [2][16 ch][P px] A rows (column = strip pixel)
         const unsigned oa_lds = lds_addr(smem + K::OFF_OA);
-        const u16* TY = (const u16*)(smem + K::OFF_TY + wq * K::NTY * TBY);
+        const u16* TY = (const u16*)(smem + K::OFF_TY + wq * K::WSY);
         const unsigned ty_lds = lds_addr(smem + K::OFF_TY);
         s16x4 bop[7][3];
 #pragma unroll
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
         f32x4 biasq = {bv7, bv7, bv7, bv7};
         // operand roles swapped like the producer's (A = Toeplitz^T, B = pixels: the same register contents, the same products): lane 4 b + j
         // holds pixels 16 t + 4 j .. + 3 of channel b - one 8-byte LDS write per tile
-        u16* oaw = OA + blk * P + SK * (blk >> 3) + 4 * q;
+        u16* oaw = OA + blk * P + SKO * (blk >> 3) + 4 * q;
         auto stage_cvt = [&](unsigned (&pk)[2 * NT], f32x4 (&av)[NT]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -390,11 +397,11 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             }
         };
         auto stage_write1 = [&](const unsigned (&pk)[2 * NT], int ob, int t) {
-            *(u32x2*)&oaw[(ob & 1) * TE + 16 * t] = u32x2{pk[2 * t], pk[2 * t + 1]};
+            *(u32x2*)&oaw[(ob & 1) * TEO + 16 * t] = u32x2{pk[2 * t], pk[2 * t + 1]};
         };
-        auto o_read = [&](u32x4 (&o)[2], int ob) { tr_row(o, oa_lds, 2, 0, ob & 1); };
-        auto y_read = [&](u32x4 (&o)[2], int buf) { tr_row(o, ty_lds, K::NTY, 4, buf); };     // T column = strip pixel + 4
-        const u16* rd = TY + blk * P + SK * (blk >> 3) + 4 * q;
+        auto o_read = [&](u32x4 (&o)[2], int ob) { tr_row(o, oa_lds, K::WSA, 0, ob & 1); };
+        auto y_read = [&](u32x4 (&o)[2], int buf) { tr_row(o, ty_lds, K::WSY, 4, buf); };     // T column = strip pixel + 4
+        const u16* rd = TY + blk * P + SKO * (blk >> 3) + 4 * q;
 
         while (g0 < g1) {
             const int col = g0 / H, ylo = g0 - col * H, yhi = min(H, ylo + (g1 - g0));
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             __builtin_amdgcn_s_barrier();
             s16x4 av0_n[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) av0_n[t] = *(const s16x4*)&rd[(2 % K::NTY) * TE + 16 * t];
+            for (int t = 0; t < NT; ++t) av0_n[t] = *(const s16x4*)&rd[(2 % K::NTY) * TEO + 16 * t];
             int r = r_lo, ob = 0, tb = 2 % K::NTY;                 // tb: T_y image of y row r = (r - r_lo + 2) % NTY
             float cand = 0.f;
 #ifdef FZ_TRACE
@@ -465,12 +472,12 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
                         if (k == 1) o_read(ov, ob ^ 1);
                         if (k == 2) {
 #pragma unroll
-                            for (int tt = 0; tt < NT; ++tt) av[1][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 4];
+                            for (int tt = 0; tt < NT; ++tt) av[1][tt] = *(const s16x4*)&rd[tb * TEO + 16 * tt + 4];
                         }
                         if (k == 3) y_read(yv, tb);
                         if (k == 70) {                               // the next row's first operands (written by the producer one iteration ago)
 #pragma unroll
-                            for (int tt = 0; tt < NT; ++tt) av0_n[tt] = *(const s16x4*)&rd[tbn * TE + 16 * tt];
+                            for (int tt = 0; tt < NT; ++tt) av0_n[tt] = *(const s16x4*)&rd[tbn * TEO + 16 * tt];
                         }
                         if (!(FZ_ABL & 16) && k == 10) o_store(ov, r - 4);
                         if (!(FZ_ABL & 16) && k == 18) y_store(yv, r);
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
                         if (k == 83) FZ_TS(4);
                         if (k == 30) {
 #pragma unroll
-                            for (int tt = 0; tt < NT; ++tt) av[2][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 8];
+                            for (int tt = 0; tt < NT; ++tt) av[2][tt] = *(const s16x4*)&rd[tb * TEO + 16 * tt + 8];
                         }
                         if (k == 62) {
                             asm volatile("" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
@@ -583,15 +590,16 @@ static int fz_rows_per_wg(long long total_rows, int ncb)       // total_rows: of
     return (int)(per_group < 16 ? 16 : per_group);
 }
 
-// 1 = this kernel takes the shape; force: ignore the launch-size rule (tests).  By itself the tower takes it from 32 output rows per CU
-// on (B = 32 at 1024^2: 96 rows at C = 192, 48 at C = 384): below that the halo rows and the serial march of one workgroup per CU lose to the
-// finer tiles of the two-kernel route.
+// 1 = this kernel takes the shape; force: ignore the launch-size rule (tests).  By itself the tower takes it from 6 output rows per CU on
+// (B >= 4 at 1024^2; profiles/r06_dw_mix_small_batch.log: B = 4 / 8 / 16 / 32 -> -17 / -15 / -20 / -20 % at C = 192, -2 / -17 / -14 / -15 %
+// at C = 384 against the two launches); below that a 16-row run per workgroup no longer gives every CU a workgroup and the finer tiles of
+// the two-kernel route win.
 extern "C" int fvhd_dw3_dw7_supported(int B, int H, int W, int C, int force)
 {
     if (!(C % 64 == 0 && W % 4 == 0 && W >= 16 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
     if (force) return 1;
     const long long total = (long long)B * (C / 64) * ((W + 63) / 64) * H;       // output rows x channel blocks: 32 per CU
-    return W >= 32 && total >= 32ll * fz_cu_count();
+    return W >= 32 && total >= 6ll * fz_cu_count();
 }
 
 template <bool AMAX, bool MASKALL>
@@ -629,6 +637,6 @@ extern "C" int fvhd_launch_dw3_dw7(hipStream_t st, const void* x, void* y, void*
 #ifdef FZ_TRACE
 extern "C" int fvhd_debug_fz_trace(unsigned long long* out, int n)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_trace_buf), sizeof(unsigned long long) * (n < 512 ? n : 512));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_trace_buf), sizeof(unsigned long long) * (n < 1024 ? n : 1024));
 }
 #endif

@@ -301,7 +301,7 @@ def bench_gemmsmall():
     raw.fvhd_debug_set_gemm_v2(1)
 
 
-def bench_dw37(B=32):
+def bench_dw37(B=int(os.environ.get("BENCH_B", "32"))):
     """RepMixer dw3x3 -> ConvFFN dw7x7: the two-kernel route against the fused launch (csrc/dwconv_fused.hip), interleaved rounds on one box;
     with the debug library also a sweep of the fused kernel's output rows per workgroup (fvhd_debug_set_fz_rc)"""
     raw = C.CDLL(_lib.LIB_PATH)
@@ -321,7 +321,7 @@ def bench_dw37(B=32):
         print(f"dw3+dw7 C={Cc:4d} {H}x{H} B={B}: two launches {t2*1e6:7.1f} us ({4*by/t2/1e12:.2f} TB/s of 4 passes)   fused {t1*1e6:7.1f} us "
               f"({3*by/t1/1e12:.2f} TB/s of 3 passes)   rounds {[(round(r[0]*1e6, 1), round(r[1]*1e6, 1)) for r in rounds]}")
         if hasattr(raw, "fvhd_debug_set_fz_rc"):
-            for rc in (16, 24, 32, 48, 64, 96, 128):
+            for rc in ((8, 12, 16, 24, 32) if B < 16 else (16, 24, 32, 48, 64, 96, 128)):
                 raw.fvhd_debug_set_fz_rc(rc)
                 print(f"    output rows per workgroup {rc:3d}: {timeit(one, iters=30)*1e6:7.1f} us")
             raw.fvhd_debug_set_fz_rc(0)

@@ -19,20 +19,18 @@ for Cc, H, B in ((384, 64, 32), (192, 128, 32)):
     for _ in range(5):
         _lib.check(lib.fvhd_op_dw3_dw7(st(), p(x), p(y), p(a), p(w3), p(b3), p(w7), p(b7), B, H, H, Cc, None))
     torch.cuda.synchronize()
-    buf = (C.c_uint64 * 512)()
-    raw.fvhd_debug_fz_trace(buf, 512)
+    buf = (C.c_uint64 * 1024)()
+    raw.fvhd_debug_fz_trace(buf, 1024)
     v = list(buf)
-    print(f"--- C={Cc} {H}x{H} B={B}: [block][role][iteration]: barrier->mfma0, ->third1, ->third2, ->last mfma, ->tail wait start, wait, barrier+, iteration total")
-    for blk in range(2):
-        for role in range(2):
-            rows = []
-            for it in range(16):
-                t = v[((blk * 2 + role) * 16 + it) * 8:][:8]
-                rows.append(t)
-            for it in range(1, 15):
-                t, nxt = rows[it], rows[it + 1]
+    # record dumped at the head of iteration it: ts[0..4] of iteration it - 1 (after its barrier, MFMA 0, thirds, last MFMA),
+    # ts[5] / ts[6] = before / after the tail wait at the head of iteration it (= the end of iteration it - 1)
+    print(f"--- C={Cc} {H}x{H} B={B}, block 7: [role][wave][iteration]: barrier->mfma0, thirds..., ->tail, tail wait | busy (release -> arrival) | barrier wait | total")
+    for role in range(2):
+        for wq in range(4):
+            recs = [v[(((role * 4 + wq) * 16 + it) * 8):][:8] for it in range(16)]
+            for it in range(2, 8):
+                t, nxt = recs[it], recs[it + 1]
                 if not t[0] or not nxt[0]:
                     continue
-                # ts[5], ts[6] stamped in iteration it + 1's head belong to the END of iteration it (they are dumped with iteration it + 1)
-                print(f"  block {'0' if blk == 0 else '77'} {'producer' if role == 0 else 'consumer'} it {it + 9:3d}: "
-                      f"{t[1] - t[0]:5d} {t[2] - t[1]:5d} {t[3] - t[2]:5d} {t[4] - t[3]:5d} | {nxt[5] - t[4]:5d} {nxt[6] - nxt[5]:5d} {nxt[0] - nxt[6]:5d} | {nxt[0] - t[0]:6d}")
+                print(f"  {'producer' if role == 0 else 'consumer'} {wq} it {it + 8:3d}: {t[1] - t[0]:5d} {t[2] - t[1]:5d} {t[3] - t[2]:5d} {t[4] - t[3]:5d} {t[5] - t[4]:5d} {t[6] - t[5]:4d} | "
+                      f"{t[6] - t[0]:5d} | {nxt[0] - t[6]:5d} | {nxt[0] - t[0]:6d}")
