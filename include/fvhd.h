@@ -144,7 +144,10 @@ int fvhd_audit_ranges(fvhd_ctx* ctx, const void* images, int img_dtype, int batc
  *                                        zero, < 0 if the block can never run the half form).
  *   fvhd_range_guard_poll              - consume the finished read-backs (wait != 0: all outstanding ones, synchronising on their events);
  *                                        steps_out / amax_out [max_out] receive the steps switched since the last poll and the max|A| that
- *                                        did it, *n_out how many. */
+ *                                        did it, *n_out how many; with max_out <= 0 nothing is handed out and nothing forgotten: *n_out = the
+ *                                        number waiting (a count query).
+ * Run-ahead: four read-backs can be in flight; a fifth fvhd_encode* call whose predecessors' read-backs nobody has consumed waits on the host
+ * for the oldest one's event (an asynchronous caller runs at most four encodes ahead of the GPU). */
 int fvhd_set_range_guard(fvhd_ctx* ctx, int on);
 int fvhd_range_guard_limit(const fvhd_ctx* ctx, int step, float* limit_out);
 int fvhd_range_guard_poll(fvhd_ctx* ctx, int wait, int* steps_out, float* amax_out, int max_out, int* n_out);

@@ -183,14 +183,23 @@ class Context:
         groups = {}
         for k, v in items:
             groups.setdefault((v.device, v.dtype), []).append((k, v))
-        for (_dev, _dt), grp in groups.items():
-            flat = torch.cat([v.reshape(-1) for _, v in grp]).to(dtype=torch.float32).cpu().contiguous()
-            off = 0
-            for k, v in grp:
-                n = v.numel()
-                shape = (C.c_int64 * max(1, v.dim()))(*v.shape)
-                check(load().fvhd_set_tensor(self._h, k.encode(), C.c_void_p(flat.data_ptr() + 4 * off), shape, v.dim()), f"fvhd_set_tensor({k})")
-                off += n
+        CHUNK = 32 << 20                                   # elements per transfer: the device-side concatenation (and its fp32 copy when the
+        for (_dev, _dt), grp in groups.items():            # tensors are 16-bit) stay below ~200 MB however large the tower (round 6, advisor)
+            i = 0
+            while i < len(grp):
+                j, n_el = i, 0
+                while j < len(grp) and (j == i or n_el + grp[j][1].numel() <= CHUNK):
+                    n_el += grp[j][1].numel()
+                    j += 1
+                part = grp[i:j]
+                flat = torch.cat([v.reshape(-1) for _, v in part]).cpu().to(dtype=torch.float32).contiguous()   # cast on the host
+                off = 0
+                for k, v in part:
+                    n = v.numel()
+                    shape = (C.c_int64 * max(1, v.dim()))(*v.shape)
+                    check(load().fvhd_set_tensor(self._h, k.encode(), C.c_void_p(flat.data_ptr() + 4 * off), shape, v.dim()), f"fvhd_set_tensor({k})")
+                    off += n
+                i = j
 
     def finalize(self) -> None:
         check(load().fvhd_finalize_weights(self._h), "fvhd_finalize_weights")

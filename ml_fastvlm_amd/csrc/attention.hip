@@ -98,11 +98,12 @@ extern "C" int fvhd_launch_layernorm(hipStream_t st, const void* x, void* y, con
 // v_mfma_f32_16x16x32_fp8_fp8 holds k = 8g..8g+7 in one 64-bit register pair - the bf16 fragment layout at half the bytes.
 // Saturating (round 5, advisor): the gfx950 conversion turns |x| > 448 into NaN - one such element of Q / K / V would poison a whole softmax
 // row where the bf16 path has no such limit - so the values are clamped to the e4m3 range first (v_med3_f32, what HIP's satfinite
-// conversions do); a NaN input stays NaN.
+// conversions do).  v_med3_f32 alone would turn a NaN into -448 (with a NaN operand it returns the minimum of the three): a NaN input is
+// passed through instead, so that it reaches the output as it does on the bf16 path (round 6, advisor).
 FVHD_DEV long pack_fp8x8(f32x8 v)
 {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], -448.0f, 448.0f);
+    for (int i = 0; i < 8; ++i) v[i] = (v[i] != v[i]) ? v[i] : __builtin_amdgcn_fmed3f(v[i], -448.0f, 448.0f);
     int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
     int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);

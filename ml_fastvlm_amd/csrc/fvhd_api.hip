@@ -532,7 +532,9 @@ bool guard_check_slot(fvhd_ctx* c, const GuardSlot& sl)
         for (int k = 0; k < kAmaxSlots; ++k) bits = sl.host[(size_t)i * kAmaxSlots + k] > bits ? sl.host[(size_t)i * kAmaxSlots + k] : bits;
         float a;
         memcpy(&a, &bits, 4);
-        if (!(a <= (c->guard_site == 1 ? f->guard_limit_y : f->guard_limit))) {   // also NaN / Inf (they sort above every finite value in the reduction)
+        // (+Inf sorts above every finite value and trips the guard.  A NaN in A does NOT: the kernels reduce with fmaxf, which drops NaN
+        // operands - a NaN activation reaches the output on either form of the block, the guard is about finite overflow only.)
+        if (!(a <= (c->guard_site == 1 ? f->guard_limit_y : f->guard_limit))) {
             f->precision = FVHD_FFN_BF16;
             c->guard_hits.push_back(GuardHit{i, a});
             switched = true;
@@ -1182,8 +1184,9 @@ int fvhd_range_guard_poll(fvhd_ctx* c, int wait, int* steps_out, float* amax_out
         if (steps_out) steps_out[i] = c->guard_hits[i].step;
         if (amax_out) amax_out[i] = c->guard_hits[i].amax;
     }
-    *n_out = n < max_out ? n : (max_out > 0 ? max_out : 0);
-    if (n <= max_out || max_out <= 0) c->guard_hits.clear();
+    if (max_out <= 0) { *n_out = n; return 0; }     // count query: nothing is handed out, nothing is forgotten (round 6, advisor)
+    *n_out = n < max_out ? n : max_out;
+    if (n <= max_out) c->guard_hits.clear();
     else c->guard_hits.erase(c->guard_hits.begin(), c->guard_hits.begin() + max_out);
     return 0;
 }

@@ -428,9 +428,17 @@ int fvhd_llm_prefill(fvhd_llm* c, const void* embeds, int dtype, const uint8_t* 
         // tensors re-set after fvhd_llm_finalize: this prefill runs behind their copies (a captured stream cannot wait on an outside
         // event - there the host waits once)
         if (c->load_pending) {
-            if (hipEventQuery(c->load_ev) == hipSuccess) c->load_pending = false;
-            else if (capturing || st == c->load_stream) { if (capturing && (e = wait_for_loads(c))) return e; }
-            else {
+            // hipEventQuery / hipEventSynchronize are not capture-safe under the default (global) capture mode: while the caller's stream is
+            // capturing they run in relaxed mode, so that they cannot invalidate the caller's capture (round 6, advisor)
+            hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+            if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);
+            const hipError_t q = hipEventQuery(c->load_ev);
+            if (q == hipSuccess) c->load_pending = false;
+            else if (capturing) e = wait_for_loads(c);
+            if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);
+            if (q != hipSuccess && q != hipErrorNotReady) (void)hipGetLastError();
+            if (e) return e;
+            if (c->load_pending && !capturing && st != c->load_stream) {
                 const hipError_t he = hipStreamWaitEvent(st, c->load_ev, 0);
                 if (he != hipSuccess) return lhip("hipStreamWaitEvent(llm weights)", he);
             }
