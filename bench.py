@@ -259,6 +259,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    if world > 1:
+        # N ranks build their synthetic weights (and pack them on the host) at the same time: each keeps to its share of the cores instead of
+        # N OpenMP teams of all cores fighting (8 ranks on one box: minutes of start-up otherwise; nothing inside the timed region runs on the CPU)
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     if args.same_device:
         if args.backend != "gloo":
             raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one device)")

@@ -47,6 +47,9 @@ constexpr int FZ_SK = 32;         // channels 8..15 start 64 B later (dwconv_mfm
 #define FZ_RS_ 4
 #endif
 constexpr int FZ_RS = FZ_RS_;     // raw-row ring depth
+#ifndef FZ_SIDE_VALU              // 1: the two neighbour-pixel products of a segment (kx = -1 of its first, kx = +1 of its last output) as fp32 FMAs on
+#define FZ_SIDE_VALU 1            // the VALU (exact fp32 taps) instead of a second pair of MFMAs: 30 instead of 60 producer MFMAs per row
+#endif
 #ifndef FZ_ABL                    // timing-only ablations (wrong results): 1 no producer MFMAs, 2 no consumer MFMAs, 4 no transposing writes,
 #define FZ_ABL 0                  // 8 no staging writes, 16 no global stores, 32 no LDS-DMA inside the row loop, 64 no per-row barrier (racy)
 #endif
@@ -182,6 +185,14 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             const u16 lh = fz_bf16_rne(vl), ll = fz_bf16_rne(vl - fz_bf16_f32(lh)), rh = fz_bf16_rne(vr), rl = fz_bf16_rne(vr - fz_bf16_f32(rh));
             tsh[ky] = s16x4{(short)lh, (short)rh, 0, 0}; tsl[ky] = s16x4{(short)ll, (short)rl, 0, 0};
         }
+        // FZ_SIDE_VALU: the neighbour taps in fp32.  In the D' layout a lane holds all four outputs of ITS segment, so every lane applies
+        // tap kx = 0 to (left neighbour pixel -> its output 0) and tap kx = 2 to (right neighbour pixel -> its output 3)
+        float wl[3], wr[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            wl[ky] = w3[(size_t)(ky * 3 + 0) * C + c0 + blk];
+            wr[ky] = w3[(size_t)(ky * 3 + 2) * C + c0 + blk];
+        }
         const float bv3 = b3 ? b3[c0 + blk] : 0.f;
         f32x4 biasq = {bv3, bv3, bv3, bv3};
         // side operands {left pixel, right pixel, 0, 0}: five fixed register pairs whose upper halves stay zero for the whole kernel
@@ -200,10 +211,11 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             const char* ximg = (const char*)(x + (size_t)n * H * W * C);
             asm volatile("" : "+v"(biasq));
             f32x4 acc[3][5];
+            float sdl[3][5], sdr[3][5];                          // FZ_SIDE_VALU: neighbour-pixel sums of the three live y rows (outputs 0 and 3 of a segment)
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
-                for (int t = 0; t < 5; ++t) acc[sl][t] = biasq;
+                for (int t = 0; t < 5; ++t) { acc[sl][t] = biasq; sdl[sl][t] = 0.f; sdr[sl][t] = 0.f; }
             unsigned tdst[3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -301,6 +313,54 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
 #pragma unroll
                     for (int t = 0; t < 5; ++t) { xc[t] = xc_n[t]; xl[t] = xl_n[t]; xr_[t] = xr_n[t]; }     // fetched during the previous iteration
                     __builtin_amdgcn_sched_barrier(0);
+#if FZ_SIDE_VALU
+                    // 30 MFMAs in the order (tap row ky = 2, 1, 0; centre-hi, centre-lo; tile): an accumulator is updated every 5th MFMA.  y row
+                    // slots: ky = 0 starts row m = p (slot u, C = the bias quad), ky = 1 -> (u + 2) % 3, ky = 2 finishes (u + 1) % 3.  The
+                    // neighbour pixels go through 2 x 3 fp32 FMAs per tile into side sums that join the accumulators when the row is finished.
+                    float fl[5], fr[5];
+#pragma unroll
+                    for (int k = 0; k < 30; ++k) {
+                        const int ky = 2 - k / 10, ty = (k % 10) / 5, t = k % 5;
+                        const int sl = ky == 0 ? u : ky == 1 ? (u + 2) % 3 : (u + 1) % 3;
+                        if (FZ_ABL & 1) {
+                            asm volatile("" : "+v"(acc[sl][t]) : "v"(xc[t]), "v"(tch[ky]), "v"(tcl[ky]));
+                        } else if (ky == 0 && ty == 0) {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[sl][t]) : "v"(tch[ky]), "v"(xc[t]), "v"(biasq));
+                        } else if (ty == 0) {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tch[ky]), "v"(xc[t]));
+                        } else {
+                            asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][t]) : "v"(tcl[ky]), "v"(xc[t]));
+                        }
+                        if (k == 1) tr_read(tv, nslot);
+                        if (!(FZ_ABL & 32) && k == 3) dma(p + RS, slot);
+                        if (k < 5) {                                  // neighbour pixels of tile k as fp32 (bf16 << 16) and their three tap rows
+                            fl[k] = __uint_as_float(xl[k] << 16);
+                            fr[k] = __uint_as_float(xr_[k] << 16);
+                            const int s2 = (u + 1) % 3, s1 = (u + 2) % 3, s0 = u;
+                            sdl[s2][k] = __builtin_fmaf(wl[2], fl[k], sdl[s2][k]); sdr[s2][k] = __builtin_fmaf(wr[2], fr[k], sdr[s2][k]);
+                            sdl[s1][k] = __builtin_fmaf(wl[1], fl[k], sdl[s1][k]); sdr[s1][k] = __builtin_fmaf(wr[1], fr[k], sdr[s1][k]);
+                            sdl[s0][k] = wl[0] * fl[k];                         sdr[s0][k] = wr[0] * fr[k];     // the slot's new row starts here
+                        }
+                        if (k == 0) FZ_TS(1);
+                        if (k == 10) FZ_TS(2);
+                        if (k == 20) FZ_TS(3);
+                        if (k == 29) FZ_TS(4);
+                        if (!(FZ_ABL & 4) && k >= 5 && k < 13) tr_write1(tv, tb ^ 1, 0, k - 5);
+                        if (k >= 13 && k < 18) {
+                            // the finished row's last MFMA was 5 .. 9: pin its readers behind this position (asm MFMAs get no hazard padding)
+                            const int tt = k - 13, fs = (u + 1) % 3;
+                            asm volatile("" : "+v"(acc[fs][tt]));
+                            yq[tt][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][0] + sdl[fs][tt], acc[fs][tt][1]}, bf16x2_t));
+                            yq[tt][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{acc[fs][tt][2], acc[fs][tt][3] + sdr[fs][tt]}, bf16x2_t));
+                            if (MASKALL || tt == 0 || tt == 4) { yq[tt][0] &= msk[tt]; yq[tt][1] &= msk[tt]; }
+                            *(u32x2*)&tyw[tyb * TEO + 16 * tt] = u32x2{yq[tt][0], yq[tt][1]};
+                        }
+                        if (!(FZ_ABL & 4) && k >= 13 && k < 21) tr_write1(tv, tb ^ 1, 1, k - 13);
+                        if (!(FZ_ABL & 4) && k >= 21 && k < 29) tr_write1(tv, tb ^ 1, 2, k - 21);
+                        if (k == 29) x_fetch(xr + 1, tb ^ 1);          // row p + 1's image is complete (its last chunk went in at k = 21 .. 28)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
                     // 60 MFMAs in the order (tap row ky = 2, 1, 0; operand centre-hi, centre-lo, side-hi, side-lo; tile): an accumulator is
                     // updated every 5th MFMA.  y row slots: ky = 0 starts row m = p (slot u, C = the bias quad), ky = 1 -> (u + 2) % 3,
                     // ky = 2 finishes (u + 1) % 3.
@@ -350,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
                         if (!(FZ_ABL & 4) && k >= 28 && k < 36) tr_write1(tv, tb ^ 1, 2, k - 28);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#endif
                     slot = nslot;
                     tb ^= 1;
                     tyb = tyb + 1 == K::NTY ? 0 : tyb + 1;
@@ -421,12 +482,12 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[sl][t] = biasq;
             auto o_store = [&](const u32x4 (&o)[2], int yo) {
-                const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;
+                const unsigned ro = (FZ_ABL & 128) ? 0u : (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;   // 128: every row onto row 0 (L2-resident lines)
                 __builtin_amdgcn_raw_buffer_store_b128(o[0], ra, (vst0 + ro) | oob0 | oobr, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o[1], ra, (vst1 + ro) | oob1 | oobr, 0, 0);
             };
             auto y_store = [&](const u32x4 (&o)[2], int yo) {      // the RepMixer output row the 7x7 is reading: stored by its own chunk only
-                const unsigned ro = (unsigned)yo * row_bytes, oobr = (yo >= ylo && yo < yhi) ? 0u : 0x80000000u;
+                const unsigned ro = (FZ_ABL & 128) ? 0u : (unsigned)yo * row_bytes, oobr = (yo >= ylo && yo < yhi) ? 0u : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(o[0], ry, (vst0 + ro) | oob0 | oobr, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o[1], ry, (vst1 + ro) | oob1 | oobr, 0, 0);
             };

@@ -76,6 +76,7 @@ def _real_tower_worker(rank, world, port, global_batch, q):
     from ml_fastvlm_amd import distributed as D
     from ml_fastvlm_amd import synth
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # `world` processes build their synthetic weights at once: no oversubscription
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -86,7 +87,7 @@ def _real_tower_worker(rank, world, port, global_batch, q):
         images = synth.synthetic_images(global_batch, 256, seed=23).to(dev, torch.bfloat16)       # the same batch on both ranks
         ok, notes = True, []
         with torch.no_grad():
-            for hidden, side in ((896, "after"), (3584, "before")):
+            for hidden, side in (((896, "after"), (3584, "before")) if world <= 2 else (((896, "after"),) if global_batch % 2 == 0 else ((3584, "before"),))):
                 proj = fv.build_vision_projector(SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=3072, hidden_size=hidden))
                 proj.load_state_dict(synth.synthetic_projector_state_dict(hidden, 1234), strict=True)
                 proj = proj.to(dev, torch.bfloat16)
