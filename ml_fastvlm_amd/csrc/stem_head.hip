@@ -185,26 +185,34 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const T* __restrict_
     for (int i = tid; i < 9 * CO / 4; i += 256) *(f32x4*)&lw1[i * 4] = *(const f32x4*)&w1[i * 4];
 
     const int H1 = R / 2, H2 = R / 4, TXY = H2 / STEMF_T;        // stem[0] map side, stem[1] map side, tiles per side
-    constexpr int NE = 3 * STEMF_IR * STEMF_IR, NIT = (NE + 255) / 256;         // 3675 image elements under a region, 15 per thread
+    // 3 x 35 x 35 = 3675 image elements under a region.  Round 6: a thread's elements are (row 8 i + tid / 32, column tid % 32) for
+    // i = 0 .. 13 (the 105 x 32 block) and two more for the three remaining columns - rows, channel index and the LDS address are
+    // compile-time offsets from one per-thread base (the first version dealt e = i * 256 + tid and paid two divisions by 35 per element and
+    // tile, twice: ~420 of a thread's ~3400 VALU instructions per tile)
+    constexpr int NROW = 3 * STEMF_IR, NIT = 16;
     // ---- phase 0 (per tile, one tile ahead): the 3 x 35 x 35 image pixels under the region, rounded to bf16 (the tower's compute
     //      dtype), zero outside the image; they go into LDS so that the im2col gather below is two aligned ds_read_b32 per (channel,
     //      tap row) instead of three bounds-checked 2-byte global loads with 64-bit addressing
     // raw element values + a validity bit mask: NO dependent operation until the values are written to LDS one tile later, so the
     // loads really stay in flight across the two phases of the current tile (a select right behind the load would wait for it)
+    auto elem = [&](int i, int ln, int& row, int& col) {         // element i of thread ln: (row of the [105][35] region image, column)
+        if (i < 14) { row = 8 * i + (ln >> 5); col = ln & 31; }
+        else { const int t3 = ln / 3; row = (i == 14 ? 0 : 85) + t3; col = 32 + (ln - 3 * t3); if (i == 15 && ln >= 60) row = NROW; }
+    };
     auto load_image = [&](int tile, T (&v)[NIT], unsigned& okmask) {
         int ln = tid;
-        asm volatile("" : "+v"(ln));                              // opaque: keeps the 15 per-thread address chains out of the tile loop's live set
+        asm volatile("" : "+v"(ln));                              // opaque: keeps the per-thread address chains out of the tile loop's live set
         const int tx_ = tile % TXY, ty_ = (tile / TXY) % TXY, b_ = tile / (TXY * TXY);
         const int iy0 = 2 * (2 * ty_ * STEMF_T - 1) - 1, ix0 = 2 * (2 * tx_ * STEMF_T - 1) - 1;
         const T* ib = img + (size_t)b_ * 3 * R * R;
         unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = i * 256 + ln;
-            const int row = e / STEMF_IR, col = e - row * STEMF_IR;
-            const int ci = row / STEMF_IR, r = row - ci * STEMF_IR;
+            int row, col;
+            elem(i, ln, row, col);
+            const int ci = (row >= STEMF_IR) + (row >= 2 * STEMF_IR), r = row - ci * STEMF_IR;      // compile-time for all but two values of i
             const int iy = iy0 + r, ix = ix0 + col;
-            const bool ok = e < NE && iy >= 0 && iy < R && ix >= 0 && ix < R;
+            const bool ok = row < NROW && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
             v[i] = ib[ok ? (unsigned)((ci * R + iy) * R + ix) : 0u];
             m |= ok ? (1u << i) : 0u;
         }
@@ -237,10 +245,10 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const T* __restrict_
         asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = i * 256 + ln;
-            const int row = e / STEMF_IR, col = e - row * STEMF_IR;
+            int row, col;
+            elem(i, ln, row, col);
             const float fv = ((okmask >> i) & 1u) ? ld_as_f32<T>(&vimg[i], 0) : 0.0f;
-            if (e < NE) itile[row * STEMF_IS + col] = (bf16)fv;
+            if (row < NROW) itile[row * STEMF_IS + col] = (bf16)fv;
         }
     }
     __syncthreads();                  // image tile complete; every thread is past phase 2 of the previous tile (`reg` may be rewritten)

@@ -95,7 +95,7 @@ final)      # evidence of the final binary: bench line, small batches, PMC passe
     timeout 600 python bench.py > ${O}_final_bench.json 2> ${O}_final_bench.err; echo "bench rc=$?"; cut -c1-300 ${O}_final_bench.json
     timeout 300 python bench.py --batch 8 --no-cpu-baseline --no-ttft > ${O}_bench_b8.json 2>/dev/null; cut -c1-200 ${O}_bench_b8.json
     timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-ttft > ${O}_bench_b1.json 2>/dev/null; cut -c1-200 ${O}_bench_b1.json
-    timeout 300 python tools/power_probe.py ffn384 ffn192 ffn96 stem attn 2>/dev/null | tee ${O}_final_power.log
+    timeout 300 python tools/power_probe.py ffn384 ffn192 ffn96 dwmix192 dwmix384 stem attn 2>/dev/null | tee ${O}_final_power.log
     bash tools/run_pmc.sh ${TAG}
     # kernel trace of the TTFT path (encode B = 8 -> splice -> Qwen2-0.5B prefill): per-layer launch times of the prefill
     timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_ttft_trace -o ttft -- python bench.py --ttft --steps 4 --warmup 1 > gpurun_out/${TAG}_ttft_trace.log 2>&1

@@ -114,6 +114,17 @@ def dw7(Cc=192):
     return (lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 7, 1, 1, 0))), 2.0 * y.numel() * 49, (x, y, w, bias)
 
 
+def dwmix(Cc=192):
+    """RepMixer dw3x3 -> ConvFFN dw7x7 in one launch (csrc/dwconv_fused.hip, round 6)"""
+    B, H = int(os.environ.get("FVHD_PROBE_B", "32")), {192: 128, 384: 64}[Cc]
+    x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+    y, a = torch.empty_like(x), torch.empty_like(x)
+    w3, b3 = torch.randn(9, Cc, device=DEV) * 0.15, torch.randn(Cc, device=DEV) * 0.2
+    w3[4] += 1.0
+    w7, b7 = torch.randn(49, Cc, device=DEV) / 7, torch.randn(Cc, device=DEV) * 0.2
+    return (lambda: _lib.check(lib.fvhd_op_dw3_dw7(stream(), p(x), p(y), p(a), p(w3), p(b3), p(w7), p(b7), B, H, H, Cc, None))), 2.0 * y.numel() * 58, (x, y, a, w3, b3, w7, b7)
+
+
 def attn():
     B, N, Cc = 32, 1024, 768
     qkv = torch.randn(B * N, 3 * Cc).to(DEV, torch.bfloat16)
@@ -146,6 +157,8 @@ def run(name, seconds=3.0):
         fn, flops, keep = ffn(int(name[3:]))
     elif name == "gemm":
         fn, flops, keep = gemm()
+    elif name.startswith("dwmix"):
+        fn, flops, keep = dwmix(int(name[5:]))
     elif name in ("attn", "dw3", "stem"):
         fn, flops, keep = {"attn": attn, "dw3": dw3, "stem": stem}[name]()
     else:
