@@ -196,32 +196,37 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const T* __restrict_
     // raw element values + a validity bit mask: NO dependent operation until the values are written to LDS one tile later, so the
     // loads really stay in flight across the two phases of the current tile (a select right behind the load would wait for it)
     auto elem = [&](int i, int ln, int& row, int& col) {         // element i of thread ln: (row of the [105][35] region image, column)
-        if (i < 14) { row = 8 * i + (ln >> 5); col = ln & 31; }
+        if (i < 14) { row = 8 * i + ((ln >> 5) & 7); col = ln & 31; }      // (& 7: ln is opaque, the compiler needs the range to fold row / 35)
         else { const int t3 = ln / 3; row = (i == 14 ? 0 : 85) + t3; col = 32 + (ln - 3 * t3); if (i == 15 && ln >= 60) row = NROW; }
     };
-    auto load_image = [&](int tile, T (&v)[NIT], unsigned& okmask) {
+    // Buffer loads through a per-image descriptor (round 6): an element outside the image gets an out-of-range offset and comes back as
+    // zero bits - no validity mask to carry, no 64-bit address arithmetic, and none of the exec-masked branches hipcc put around every one
+    // of the 16 conditional loads of the flat form.  The raw bits ride in registers across both phases of the current tile.
+    auto load_image = [&](int tile, unsigned (&v)[NIT]) {
         int ln = tid;
         asm volatile("" : "+v"(ln));                              // opaque: keeps the per-thread address chains out of the tile loop's live set
         const int tx_ = tile % TXY, ty_ = (tile / TXY) % TXY, b_ = tile / (TXY * TXY);
         const int iy0 = 2 * (2 * ty_ * STEMF_T - 1) - 1, ix0 = 2 * (2 * tx_ * STEMF_T - 1) - 1;
-        const T* ib = img + (size_t)b_ * 3 * R * R;
-        unsigned m = 0;
+        const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (size_t)b_ * 3 * R * R), 0, (unsigned)(3 * R * R * sizeof(T)), 0x00020000);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             int row, col;
             elem(i, ln, row, col);
             const int ci = (row >= STEMF_IR) + (row >= 2 * STEMF_IR), r = row - ci * STEMF_IR;      // compile-time for all but two values of i
             const int iy = iy0 + r, ix = ix0 + col;
-            const bool ok = row < NROW && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
-            v[i] = ib[ok ? (unsigned)((ci * R + iy) * R + ix) : 0u];
-            m |= ok ? (1u << i) : 0u;
+            const bool ok = (i < 13 || row < NROW) & ((unsigned)iy < (unsigned)R) & ((unsigned)ix < (unsigned)R);     // '&': selects, not branches
+            const unsigned off = ok ? (unsigned)(((ci * R + iy) * R + ix) * (int)sizeof(T)) : 0xffffffffu;
+            if constexpr (sizeof(T) == 4) v[i] = __builtin_amdgcn_raw_buffer_load_b32(rimg, off, 0, 0);
+            else v[i] = __builtin_amdgcn_raw_buffer_load_b16(rimg, off, 0, 0);
         }
-        okmask = m;
     };
-    T vimg[NIT];
-    unsigned okmask = 0;
+    auto bits_as_f32 = [](unsigned bits) -> float {               // raw element bits -> its value (zero bits = 0.0 in every dtype)
+        if constexpr (sizeof(T) == 4) return __uint_as_float(bits);
+        else { const unsigned short h = (unsigned short)bits; return ld_as_f32<T>((const T*)&h, 0); }
+    };
+    unsigned vimg[NIT];
     int tile = blockIdx.x;
-    if (tile < ntiles) load_image(tile, vimg, okmask);
+    if (tile < ntiles) load_image(tile, vimg);
     __syncthreads();                                              // weight image + taps visible
     bf16x8 wa[3][2];
 #pragma unroll
@@ -247,12 +252,11 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const T* __restrict_
         for (int i = 0; i < NIT; ++i) {
             int row, col;
             elem(i, ln, row, col);
-            const float fv = ((okmask >> i) & 1u) ? ld_as_f32<T>(&vimg[i], 0) : 0.0f;
-            if (row < NROW) itile[row * STEMF_IS + col] = (bf16)fv;
+            if (i < 13 || row < NROW) itile[row * STEMF_IS + col] = (bf16)bits_as_f32(vimg[i]);
         }
     }
     __syncthreads();                  // image tile complete; every thread is past phase 2 of the previous tile (`reg` may be rewritten)
-    if (tile + (int)gridDim.x < ntiles) load_image(tile + gridDim.x, vimg, okmask);    // in flight during both phases
+    if (tile + (int)gridDim.x < ntiles) load_image(tile + gridDim.x, vimg);    // in flight during both phases
     // ---- phase 1: the stem[0] region, 32 positions per MFMA tile
 #pragma unroll 1
     for (int t = wave; t * 32 < STEMF_NP; t += 4) {
