@@ -229,7 +229,8 @@ int fvhd_op_dw7_mfma(fvhd_stream_t stream, const void* x, void* y, const float* 
  * 16-block 4x4x4 bf16 MFMA: the 3x3 with every tap split into two bf16 halves (16 mantissa bits - the re-parameterised centre tap is
  * 1 + eps), the 7x7 exactly as fvhd_op_dw7_mfma (taps rounded to bf16; the same bits as that entry point given the same y).
  * amax_bits: NULL or FVHD_AMAX_SLOTS words (zeroed by the caller) receiving max |a| as in fvhd_op_dw7_amax(mfma = 1).
- * Needs C % 64 == 0, W % 4 == 0, W >= 16; anything else is an error.  The tower takes this kernel for a RepMixerBlock by itself once
+ * Needs C % 32 == 0, C >= 64, W % 4 == 0, W >= 16; anything else is an error (C % 64 == 32 - stage 0's C = 96 - runs its last 64-channel
+ * block half masked).  The tower takes this kernel for a RepMixerBlock by itself once
  * the launch fills the chip (fvhd_dw3_dw7_supported(..., 0)); never under fvhd_set_batch_invariant. */
 int fvhd_op_dw3_dw7(fvhd_stream_t stream, const void* x, void* y, void* a, const float* w3, const float* b3, const float* w7,
                     const float* b7, int B, int H, int W, int C, void* amax_bits);

@@ -110,7 +110,12 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
     const int wq = wv & 3;                                   // channel group of this wave (producer wq and consumer wq + 4 share it)
     const int blk = lane >> 2, q = lane & 3;
     const unsigned img_bytes = (unsigned)H * W * C * 2, row_bytes = (unsigned)W * C * 2;
-    const int NCB = C / CW, cb = (int)blockIdx.x % NCB, c0 = cb * CW + wq * 16;
+    // C % 64 == 32 (C = 96: 192-B pixels): the last 64-channel block is half real.  Its lanes outside the C channels read the block's first
+    // half a second time (valid addresses, finite values), convolve with a clamped channel's taps, and never store; the waves of those
+    // channels stay out of the guard's maximum.  1.33x the work of 96 channels - still ahead of the two launches (profiles/r06_dw_mix_c96.log).
+    const int NCB = (C + CW - 1) / CW, cb = (int)blockIdx.x % NCB, c0 = cb * CW + wq * 16;
+    const int chv = min(c0 + blk, C - 1);                    // the channel whose taps this lane loads
+    const bool wave_real = c0 < C;
     int g0 = ((int)blockIdx.x / NCB) * rows_per_wg;
     const int g1 = min(g0 + rows_per_wg, total_rows);
     char* raw = smem;                                        // [RS][64 interior px | 8 halo px][PXB]
@@ -177,11 +182,11 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int kx = k - q + 1;
-                const float v = (kx >= 0 && kx < 3) ? w3[(size_t)(ky * 3 + kx) * C + c0 + blk] : 0.f;
+                const float v = (kx >= 0 && kx < 3) ? w3[(size_t)(ky * 3 + kx) * C + chv] : 0.f;
                 const u16 hi = fz_bf16_rne(v), lo = fz_bf16_rne(v - fz_bf16_f32(hi));
                 tch[ky][k] = (short)hi; tcl[ky][k] = (short)lo;
             }
-            const float vl = q == 0 ? w3[(size_t)(ky * 3 + 0) * C + c0 + blk] : 0.f, vr = q == 3 ? w3[(size_t)(ky * 3 + 2) * C + c0 + blk] : 0.f;
+            const float vl = q == 0 ? w3[(size_t)(ky * 3 + 0) * C + chv] : 0.f, vr = q == 3 ? w3[(size_t)(ky * 3 + 2) * C + chv] : 0.f;
             const u16 lh = fz_bf16_rne(vl), ll = fz_bf16_rne(vl - fz_bf16_f32(lh)), rh = fz_bf16_rne(vr), rl = fz_bf16_rne(vr - fz_bf16_f32(rh));
             tsh[ky] = s16x4{(short)lh, (short)rh, 0, 0}; tsl[ky] = s16x4{(short)ll, (short)rl, 0, 0};
         }
@@ -190,10 +195,10 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
         float wl[3], wr[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            wl[ky] = w3[(size_t)(ky * 3 + 0) * C + c0 + blk];
-            wr[ky] = w3[(size_t)(ky * 3 + 2) * C + c0 + blk];
+            wl[ky] = w3[(size_t)(ky * 3 + 0) * C + chv];
+            wr[ky] = w3[(size_t)(ky * 3 + 2) * C + chv];
         }
-        const float bv3 = b3 ? b3[c0 + blk] : 0.f;
+        const float bv3 = b3 ? b3[chv] : 0.f;
         f32x4 biasq = {bv3, bv3, bv3, bv3};
         // side operands {left pixel, right pixel, 0, 0}: five fixed register pairs whose upper halves stay zero for the whole kernel
         s16x4 xs[5];
@@ -207,7 +212,10 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             // y rows the 7x7 reads: [r_lo, r_hi) (all inside the image); x rows the 3x3 reads for them: r_lo - 1 .. r_hi (zero rows outside the image)
             const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3), nrow = r_hi - r_lo, NP = nrow + 2;
             const int ntail = max(0, yhi - max(ylo, r_hi - 3));      // output rows whose last input row lies below the image
-            auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + off); };
+            auto goff = [&](int px, int off) {                  // byte offset of (pixel, byte `off` of this block's 128); bytes beyond the C channels wrap into the block's first half
+                const int o2 = (cb * CW * 2 + off < C * 2) ? off : off - 64;
+                return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + o2);
+            };
             const char* ximg = (const char*)(x + (size_t)n * H * W * C);
             asm volatile("" : "+v"(biasq));
             f32x4 acc[3][5];
@@ -442,10 +450,10 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int kx = 4 * (sg - 1) + k - q + 3;
-                    const float v = (kx >= 0 && kx < 7) ? w7[(size_t)(ky * 7 + kx) * C + c0 + blk] : 0.f;
+                    const float v = (kx >= 0 && kx < 7) ? w7[(size_t)(ky * 7 + kx) * C + chv] : 0.f;
                     bop[ky][sg][k] = (short)fz_bf16_rne(v);
                 }
-        const float bv7 = b7 ? b7[c0 + blk] : 0.f;
+        const float bv7 = b7 ? b7[chv] : 0.f;
         f32x4 biasq = {bv7, bv7, bv7, bv7};
         // operand roles swapped like the producer's (A = Toeplitz^T, B = pixels: the same register contents, the same products): lane 4 b + j
         // holds pixels 16 t + 4 j .. + 3 of channel b - one 8-byte LDS write per tile
@@ -469,10 +477,14 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
             const int n = col / nstrip, strip = col - n * nstrip, x0 = strip * SW;
             g0 += yhi - ylo;
             const int r_lo = max(0, ylo - 3), r_hi = min(H, yhi + 3);
-            auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + off); };
+            auto goff = [&](int px, int off) {                  // byte offset of (pixel, byte `off` of this block's 128); bytes beyond the C channels wrap into the block's first half
+                const int o2 = (cb * CW * 2 + off < C * 2) ? off : off - 64;
+                return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + o2);
+            };
             const int dpx = x0 + dpxr;
-            const unsigned vst0 = goff(dpx, (ds_ & 7) * 16), oob0 = dpx < W ? 0u : 0x80000000u;
-            const unsigned vst1 = goff(dpx + 8, (ds_ & 7) * 16), oob1 = dpx + 8 < W ? 0u : 0x80000000u;
+            const bool chunk_real = cb * CW * 2 + (ds_ & 7) * 16 < C * 2;       // this lane's 8 channels exist
+            const unsigned vst0 = goff(dpx, (ds_ & 7) * 16), oob0 = (dpx < W && chunk_real) ? 0u : 0x80000000u;
+            const unsigned vst1 = goff(dpx + 8, (ds_ & 7) * 16), oob1 = (dpx + 8 < W && chunk_real) ? 0u : 0x80000000u;
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a + (size_t)n * H * W * C), 0, img_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)n * H * W * C), 0, img_bytes, 0x00020000);
             asm volatile("" : "+v"(biasq));
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
         if constexpr (AMAX) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) amx = __builtin_fmaxf(amx, __shfl_xor(amx, o, 64));
-            if (lane == 0) ((float*)(smem + K::OFF_TX))[wq] = amx;       // the producers' images are dead (end-of-segment barrier)
+            if (lane == 0) ((float*)(smem + K::OFF_TX))[wq] = wave_real ? amx : 0.f;       // the producers' images are dead (end-of-segment barrier)
         }
     }
     if constexpr (AMAX) {                                      // workgroup maximum -> one atomic per workgroup, slot by block id
@@ -657,9 +669,9 @@ static int fz_rows_per_wg(long long total_rows, int ncb)       // total_rows: of
 // the two-kernel route win.
 extern "C" int fvhd_dw3_dw7_supported(int B, int H, int W, int C, int force)
 {
-    if (!(C % 64 == 0 && W % 4 == 0 && W >= 16 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
+    if (!(C % 32 == 0 && C >= 64 && W % 4 == 0 && W >= 16 && H >= 1 && B >= 1 && (long long)H * W * C * 2 < (1ll << 31))) return 0;
     if (force) return 1;
-    const long long total = (long long)B * (C / 64) * ((W + 63) / 64) * H;       // output rows x channel blocks: 32 per CU
+    const long long total = (long long)B * ((C + 63) / 64) * ((W + 63) / 64) * H;       // output rows x channel blocks
     return W >= 32 && total >= 6ll * fz_cu_count();
 }
 
@@ -675,7 +687,7 @@ static int fz_launch(hipStream_t st, const void* x, void* y, void* a, const floa
         if (e != hipSuccess) return (int)e;
         attr_set[dev & 63] = true;
     }
-    const int nstrip = (W + 63) / 64, ncb = C / 64;
+    const int nstrip = (W + 63) / 64, ncb = (C + 63) / 64;
     const long long total = (long long)B * nstrip * H;                   // output rows of one channel block
     if (total <= 0 || total > 0x7fffffffll) return (int)hipErrorInvalidValue;
     const int rpw = fz_rows_per_wg(total, ncb);

@@ -1375,7 +1375,7 @@ int fvhd_op_dw3_dw7(fvhd_stream_t st, const void* x, void* y, void* a, const flo
     if (!x || !y || !a || !w3 || !w7) return fail("fvhd_op_dw3_dw7: NULL pointer");
     if (x == y || x == a || y == a) return fail("fvhd_op_dw3_dw7: x, y and a must be three distinct buffers");
     if (!fvhd_dw3_dw7_supported(B, H, W, C, 1))
-        return fail("fvhd_op_dw3_dw7: needs C % 64 == 0, W % 4 == 0, W >= 16 and an image below 2 GiB (got B=" + std::to_string(B) + " H=" +
+        return fail("fvhd_op_dw3_dw7: needs C % 32 == 0, C >= 64, W % 4 == 0, W >= 16 and an image below 2 GiB (got B=" + std::to_string(B) + " H=" +
                     std::to_string(H) + " W=" + std::to_string(W) + " C=" + std::to_string(C) + ")");
     int e = fvhd_launch_dw3_dw7((hipStream_t)st, x, y, a, w3, b3, w7, b7, B, H, W, C, (unsigned*)amax_bits);
     return e ? hip_fail("fvhd_op_dw3_dw7", (hipError_t)e) : 0;

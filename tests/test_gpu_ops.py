@@ -414,6 +414,9 @@ def _repmixer_taps(C, seed):
     (128, 17, 16, 2, True),      # the narrowest map
     (64, 50, 132, 1, False),     # third strip 4 px wide
     (192, 128, 128, 12, True),   # large enough for the tower's own dispatch (32-row chunks)
+    (96, 40, 64, 2, True),       # C % 64 == 32 (stage 0: 192-B pixels): the second channel block is half real - masked stores, clamped taps,
+    (96, 33, 132, 1, False),     # its waves kept out of the guard's maximum
+    (288, 21, 48, 2, True),      # 4.5 channel blocks
 ])
 def test_dw3_dw7_fused_kernel(C, H, W, B, amax):
     """fvhd_op_dw3_dw7 (csrc/dwconv_fused.hip): RepMixer dw3x3 -> ConvFFN dw7x7 in one launch.
@@ -456,7 +459,7 @@ def test_dw3_dw7_rejects_shapes_it_does_not_take():
     x = torch.zeros(1, 8, 64, 64, dtype=torch.bfloat16, device=DEV)
     y, a = torch.zeros_like(x), torch.zeros_like(x)
     w3, w7 = torch.zeros(9, 96, device=DEV), torch.zeros(49, 96, device=DEV)
-    assert lib.fvhd_op_dw3_dw7(_stream(), _p(x), _p(y), _p(a), _p(w3), None, _p(w7), None, 1, 8, 64, 96, None) != 0     # C = 96
+    assert lib.fvhd_op_dw3_dw7(_stream(), _p(x), _p(y), _p(a), _p(w3), None, _p(w7), None, 1, 8, 64, 48, None) != 0     # C = 48
     assert lib.fvhd_op_dw3_dw7(_stream(), _p(x), _p(y), _p(a), _p(w3), None, _p(w7), None, 1, 8, 18, 64, None) != 0     # W % 4
     assert lib.fvhd_op_dw3_dw7(_stream(), _p(x), _p(x), _p(a), _p(w3), None, _p(w7), None, 1, 8, 64, 64, None) != 0     # y aliases x
     assert lib.fvhd_dw3_dw7_supported(1, 64, 64, 384, 0) == 0 and lib.fvhd_dw3_dw7_supported(32, 64, 64, 384, 0) == 1

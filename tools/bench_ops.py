@@ -305,7 +305,7 @@ def bench_dw37(B=int(os.environ.get("BENCH_B", "32"))):
     """RepMixer dw3x3 -> ConvFFN dw7x7: the two-kernel route against the fused launch (csrc/dwconv_fused.hip), interleaved rounds on one box;
     with the debug library also a sweep of the fused kernel's output rows per workgroup (fvhd_debug_set_fz_rc)"""
     raw = C.CDLL(_lib.LIB_PATH)
-    shapes = [(Cc, H) for Cc, H in ((192, 128), (384, 64), (64, 256)) if lib.fvhd_dw3_dw7_supported(B, H, H, Cc, 1)]
+    shapes = [(Cc, H) for Cc, H in ((192, 128), (384, 64), (64, 256), (96, 256)) if lib.fvhd_dw3_dw7_supported(B, H, H, Cc, 1)]
     for Cc, H in shapes:
         x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
         y, a = torch.empty_like(x), torch.empty_like(x)
