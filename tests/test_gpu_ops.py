@@ -454,6 +454,19 @@ def test_dw3_dw7_fused_kernel(C, H, W, B, amax):
         assert abs(got_m - want_m) <= 1e-5 * want_m, (got_m, want_m)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_dw3_dw7_fused_kernel_random_shapes(seed):
+    """seeded random geometry: any height (row runs that end inside a column, columns shorter than a run), widths from the narrowest
+    accepted map to several strips with a ragged last one (multiples of 4), whole and half-masked channel blocks, batch 1..3"""
+    import random
+    rnd = random.Random(2000 + seed)
+    C = rnd.choice([64, 96, 128, 160, 192, 288])
+    H, W, B = rnd.randint(1, 70), 4 * rnd.randint(4, 37), rnd.randint(1, 3)
+    if C % 64 and C % 96:            # the bit-identity leg runs fvhd_op_dw7_mfma on y: that kernel takes C % 64 == 0 or C % 96 == 0
+        C = 96
+    test_dw3_dw7_fused_kernel(C, H, W, B, amax=bool(seed & 1))
+
+
 def test_dw3_dw7_rejects_shapes_it_does_not_take():
     lib = _lib.load()
     x = torch.zeros(1, 8, 64, 64, dtype=torch.bfloat16, device=DEV)

@@ -34,7 +34,7 @@ def _nhwc_bf16(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
 
 
-def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16, batch_invariant=None, replicate=1, expect_fused_ffn=None):
+def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16, batch_invariant=None, replicate=1, expect_fused_ffn=None, expect_dw_mix=None):
     """batch_invariant: the tower option (None = default per-batch kernel selection, True = selection by image shape only, which at
     B = 1 forces the big-batch kernel set: fused ConvFFN at C = 192 / 384, matrix-core dw7x7).  replicate = k: the GPU sees every
     distinct image k times (batch * k rows, expanded on the device) so that the DEFAULT selection takes the kernels of a large batch
@@ -94,6 +94,9 @@ def _run_teacher_forced(res, batch, sd, seed, param_dtype=torch.bfloat16, batch_
     if expect_fused_ffn is not None:                                # the kernel set under test is the one the caller meant to test
         assert prof["ffn_fused"][1] == expect_fused_ffn, (prof["ffn_fused"], expect_fused_ffn)
         assert prof["gemm_fc1"][1] == prof["gemm_fc2"][1] == 44 - expect_fused_ffn
+    if expect_dw_mix is not None:                                   # RepMixerBlocks whose dw3x3 + dw7x7 ran as ONE launch (round 6): the rest = two launches
+        assert prof["dw_mix"][1] == expect_dw_mix and prof["dw3"][1] == 38 - expect_dw_mix, (prof["dw_mix"], prof["dw3"])
+        assert prof["dw7"][1] == 46 - expect_dw_mix, prof["dw7"]
     for r in rows:
         print("step %2d %-16s %-28s rel-L2 %.3e  max-abs/absmax %.3e  out-of-bound %d" % r)
     bad = [r for r in rows if r[3] > STEP_REL or r[5] > 0]
@@ -123,7 +126,8 @@ def test_steps_teacher_forced_r320_ragged(synth_sd, inv):
 @pytest.mark.parametrize("inv", [None, True])
 def test_steps_teacher_forced_r1024(synth_sd, inv):
     # default selection at B = 1: only stage 0 (65536 rows) takes the fused ConvFFN
-    _run_teacher_forced(1024, 1, synth_sd, seed=5, batch_invariant=inv, expect_fused_ffn=38 if inv else 2)
+    # (one-launch depthwise pair: never under batch_invariant; by itself from 6 output rows per CU on - at B = 1 only stage 0's 2 blocks)
+    _run_teacher_forced(1024, 1, synth_sd, seed=5, batch_invariant=inv, expect_fused_ffn=38 if inv else 2, expect_dw_mix=0 if inv else 2)
 
 
 def test_steps_teacher_forced_r1024_bench_batch(synth_sd):
@@ -131,7 +135,7 @@ def test_steps_teacher_forced_r1024_bench_batch(synth_sd):
     ConvFFN at C = 96 / 192 / 384, matrix-core dw7x7 with 32-row chunks, LDS-DMA dw3x3, the 256x128 streaming GEMM for qkv / fc1 /
     fc2 / 1x1 (>= 512 tiles), every step teacher-forced against the bf16-storage emulation at the per-step tolerance.  2 distinct
     images x 16 copies: the emulation costs two images, the GPU launches are the bench's."""
-    _run_teacher_forced(1024, 2, synth_sd, seed=7, replicate=16, expect_fused_ffn=38)
+    _run_teacher_forced(1024, 2, synth_sd, seed=7, replicate=16, expect_fused_ffn=38, expect_dw_mix=38)
 
 
 def test_run_steps_chain_equals_encode(synth_sd):
