@@ -104,6 +104,61 @@ PMC_PARTS = {"ffn_fused": ["ffn_fused_c384", "ffn_fused_c192", "ffn_fused_c96"],
              "gemm_qkv": ["gemm_plain (qkv)"]}
 
 
+class PowerSampler:
+    """Package power and shader clock of the device HIP runs on while the timed steps run (sysfs hwmon of its PCI address, 25-ms period):
+    the hot kernels sit at the 1.4-kW package cap, where wall time follows JOULES per step, not cycles - so the line carries
+    them.  Absent hwmon files (or no permission) give `None`."""
+
+    def __init__(self, device_index: int):
+        import ctypes
+        import glob
+        import threading
+        self.pw, self.clk, self.cap, self.stop = [], [], None, False
+        self.pfile = self.cfile = None
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, device_index) == 0:
+                for hw in glob.glob(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/hwmon/hwmon*"):
+                    for f in ("power1_average", "power1_input"):
+                        if os.path.exists(os.path.join(hw, f)):
+                            self.pfile = os.path.join(hw, f)
+                            self.cfile = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
+                            capf = os.path.join(hw, "power1_cap")
+                            self.cap = int(open(capf).read()) / 1e6 if os.path.exists(capf) else None
+                            break
+                    if self.pfile:
+                        break
+        except Exception:
+            self.pfile = None
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.pfile else None
+
+    def _run(self):
+        while not self.stop:
+            try:
+                self.pw.append(int(open(self.pfile).read()) / 1e6)
+                if self.cfile:
+                    self.clk.append(int(open(self.cfile).read()) / 1e6)
+            except Exception:
+                pass
+            time.sleep(0.025)
+
+    def start(self):
+        if self.thread:
+            self.thread.start()
+
+    def finish(self, seconds: float, steps: int):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=1)
+        if not self.pw:
+            return None
+        mean = sum(self.pw) / len(self.pw)
+        return {"mean_w": round(mean, 1), "max_w": round(max(self.pw), 1), "cap_w": self.cap, "joules_per_step": round(mean * seconds / steps, 3),
+                "sclk_mhz": round(sum(self.clk) / len(self.clk)) if self.clk else None, "samples": len(self.pw),
+                "source": "sysfs hwmon power1 of the HIP device, sampled every 25 ms over the timed steps"}
+
+
 def pmc_summary(res: int, batch: int):
     """The newest committed rocprofv3 PMC summary (`profiles/*_pmc_summary.json`: tools/run_pmc.sh + tools/pmc_summary.py, separate
     `--pmc` passes of this same command) whose workload (`_meta`: image size, batch) is THIS run's - counters of another workload
@@ -341,6 +396,9 @@ def main():
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
+    power = PowerSampler(local_rank) if rank == 0 else None
+    if power:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -349,6 +407,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    power_obj = power.finish(dt, args.steps) if power else None
     trace("timed region done")
     assert torch.isfinite(out.float()).all()
     if multi:
@@ -373,6 +432,7 @@ def main():
                    **({"collective": f"all_gather_into_tensor over {'nccl (RCCL)' if args.backend == 'nccl' else 'gloo (host-staged; test only)'}, world {world}",
                        "gather_side": side} if multi else {})},
     }
+    result["power"] = power_obj      # package power / joules per step over the timed region (None without hwmon access)
 
     if rank == 0 and not args.no_roofline:
         ctx = tower._context()
