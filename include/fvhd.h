@@ -236,6 +236,16 @@ int fvhd_op_dw3_dw7(fvhd_stream_t stream, const void* x, void* y, void* a, const
                     const float* b7, int B, int H, int W, int C, void* amax_bits);
 /* 1 when fvhd_op_dw3_dw7 takes the shape (force != 0) / when the tower picks it by itself (force == 0) */
 int fvhd_dw3_dw7_supported(int B, int H, int W, int C, int force);
+/* 1 when fvhd_op_dwconv runs PatchEmbed's depthwise conv (K = 7, stride 2, mult 2; mci.py:442-451) on the matrix cores (round 6,
+ * csrc/dwconv_down.hip: stride 2 as two Toeplitz products over the even and the odd input pixels, taps rounded to bf16 as in fvhd_op_dw7_mfma,
+ * fp32 accumulation, fp32 GELU): C_in % 32 == 0 and, for force == 0, an output map at least 24 pixels wide (narrower maps: the VALU
+ * kernel's finer tiles).  A choice by shape only - the same bits whatever the batch.  The TOWER additionally keeps the VALU kernel (fp32
+ * taps) for a PatchEmbed whose packed taps are not bf16 numbers (an fp32 / fp16 checkpoint): with a re-parameterised bf16 checkpoint the
+ * kernel's bf16 operands are the taps themselves.  FVHD_DWDOWN_MFMA=0 in the environment keeps the VALU kernel everywhere. */
+int fvhd_dw7s2_mfma_supported(int B, int H, int W, int Cin, int force);
+/* the same conv on that kernel directly: x [B,H,W,Cin] -> y [B,ceil(H/2),ceil(W/2),2 Cin] NHWC bf16, w fp32 [49][2 Cin], bias fp32 [2 Cin] or
+ * NULL, GELU applied; any shape with fvhd_dw7s2_mfma_supported(..., 1) */
+int fvhd_op_dw7s2_mfma(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int Cin);
 #define FVHD_AMAX_SLOTS 64
 int fvhd_op_dw7_amax(fvhd_stream_t stream, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, int mfma,
                      void* amax_bits);

@@ -50,6 +50,8 @@ def _declare(lib) -> None:
         "fvhd_op_dw7_mfma": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci]),
         "fvhd_op_dw3_dw7": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
         "fvhd_dw3_dw7_supported": (ci, [ci, ci, ci, ci, ci]),
+        "fvhd_dw7s2_mfma_supported": (ci, [ci, ci, ci, ci, ci]),
+        "fvhd_op_dw7s2_mfma": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci]),
         "fvhd_op_gemm": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
         "fvhd_op_gemm_splitk_ls": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci]),
         "fvhd_gemm_splitk_plan": (ci, [ci, ci, ci]),

@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libfvhd.so")
-SOURCES = ["dwconv.hip", "dwconv_mfma.hip", "dwconv_fused.hip", "gemm.hip", "attention.hip", "stem_head.hip", "ffn_fused.hip", "splice.hip", "preprocess.hip", "llm.hip", "llm_api.hip", "fvhd_api.hip"]
+SOURCES = ["dwconv.hip", "dwconv_mfma.hip", "dwconv_fused.hip", "dwconv_down.hip", "gemm.hip", "attention.hip", "stem_head.hip", "ffn_fused.hip", "splice.hip", "preprocess.hip", "llm.hip", "llm_api.hip", "fvhd_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-fno-gpu-rdc"]
@@ -42,7 +42,9 @@ EXTRA_FLAGS = {"ffn_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll
                # dwconv_mfma.hip: 7 x 84 hand-placed MFMA slots, every register-array index compile-time (768 B/lane of scratch otherwise)
                "dwconv_mfma.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
                # dwconv_fused.hip: the same row loops (3 x 60 producer slots, 7 x 84 consumer slots)
-               "dwconv_fused.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+               "dwconv_fused.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+               # dwconv_down.hip: 4 x 56 slots; NOPK: its GELU runs beside the MFMAs
+               "dwconv_down.hip": ["-mllvm", "-pragma-unroll-threshold=200000"] + NOPK}
 
 
 def _hipcc() -> str:

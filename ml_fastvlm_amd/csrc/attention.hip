@@ -92,6 +92,11 @@ extern "C" int fvhd_launch_layernorm(hipStream_t st, const void* x, void* y, con
 #define ATT_QW 2           // 16-query blocks per wave: every K / V^T fragment read from LDS feeds ATT_QW MFMAs
 #endif
 #define ATT_QB (64 * ATT_QW)   // queries per workgroup
+#ifndef ATT_VTR
+#define ATT_VTR 1          // 1: bf16 V staged row-major and transposed by ds_read_b64_tr_b16 (round 6); 0: the round-1 ds_write_b16 transposition (A/B)
+#endif
+typedef short att_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) att_s16x4* att_lds_s16x4p;
 #define ATT_VT_STRIDE 136  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
 
 // fp8 (OCP e4m3, round to nearest even) pack of 8 fp32 values, k-slot order preserved: the operand of
@@ -153,6 +158,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
     // fp8 K tile: 32-B rows, 8-B slot s of row r at slot s ^ (2 * ((r >> 3) & 1)): the 32 lanes of one ds_read_b64 group
     // (16 rows x 2 slots) then cover all 64 banks once
     const int k8_dst = skey * 32 + ((sch ^ (((skey >> 3) & 1) << 1)) << 3);
+    // bf16 V tile (round 6): row-major [key][32 d] like K, 64-B rows; the 32-B half (d 0..15 | 16..31) of a row is swapped for keys with
+    // (key >> 2) & 1, so that the 8 keys x 32 B a half-wave of a transposing read touches cover all 64 banks once.
+    // v_dst: this thread's 16-B chunk sch of key skey; v_src: this lane's source role for the transposing read (see the PV loop)
+    const int v_dst = skey * 64 + ((sch ^ (((skey >> 2) & 1) << 1)) << 4);
+    const unsigned v_src = lds_addr(lds) + (unsigned)(ATT_KT * 64 + (4 * g + (lr >> 2)) * 64 + (lr & 3) * 8);
 
     f32x4 o_acc[ATT_QW][2];                              // O^T[d = df*16 + 4g + r][q = lr]
     // softmax denominators on the matrix cores: a third "V^T fragment" of ones makes every row of l_acc the sum over the keys of the
@@ -191,9 +201,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
             for (int i = 0; i < 8; ++i) *(unsigned char*)(vbuf + (sch * 8 + i) * ATT_VT8_STRIDE + skey) = (unsigned char)(v8 >> (8 * i));
         } else {
             *(u32x4*)(kbuf + k_dst) = rk;
+#if ATT_VTR
+            *(u32x4*)(vbuf + v_dst) = rv;               // V row-major like K: transposed by the READ (ds_read_b64_tr_b16), not by 8 ds_write_b16
+#else
             const bf16x8 vv = __builtin_bit_cast(bf16x8, rv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) *(bf16*)(vbuf + (sch * 8 + i) * ATT_VT_STRIDE + skey * 2) = vv[i];
+#endif
         }
         __syncthreads();
         if (t + 1 < ntiles) {
@@ -290,10 +304,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16* __restrict__
                     for (int w = 0; w < ATT_QW; ++w)
                         o_acc[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vf, pf8[w][c], o_acc[w][df], 0, 0, 0);
                 } else {
+#if ATT_VTR
+                    // lane (g, lr = 4 x + e) gets element e of the 8 bytes source lanes 4 j + x (j = 0..3) address: source lane (g, j, x) points at
+                    // d = df*16 + 4 x .. + 3 of key c*32 + 4 g + j (+ 16 for the second half) -> 4 consecutive keys of d = df*16 + lr
+                    const unsigned va = v_src + (unsigned)((t & 1) * (ATT_KT * 64 + ATT_D * ATT_VT_STRIDE) + c * 32 * 64) + (unsigned)((df ^ (g & 1)) << 5);
+                    const att_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4p)(size_t)va);
+                    const att_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4p)(size_t)(va + 16 * 64));
+                    const bf16x4 lo = __builtin_bit_cast(bf16x4, lo4), hi = __builtin_bit_cast(bf16x4, hi4);
+                    const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#else
                     const char* vr = vbuf + (df * 16 + lr) * ATT_VT_STRIDE + (c * 32 + g * 4) * 2;
                     const bf16x4 lo = *(const bf16x4*)(vr);
                     const bf16x4 hi = *(const bf16x4*)(vr + 32);
                     const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
 #pragma unroll
                     for (int w = 0; w < ATT_QW; ++w)
                         o_acc[w][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[w][c], o_acc[w][df], 0, 0, 0);

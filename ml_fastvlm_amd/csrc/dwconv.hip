@@ -320,13 +320,20 @@ static hipError_t launch_dw_tiled(hipStream_t st, const bf16* x, bf16* y, const 
 // x [B,H,W,Cin] bf16 -> y [B,OH,OW,Cin*mult] bf16; w fp32 [K*K][Cout]; bias fp32 [Cout] or null.
 extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force);
 extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax);
+extern "C" int fvhd_dw7s2_mfma_supported(int B, int H, int W, int Cin, int force);
+extern "C" int fvhd_launch_dw7s2_mfma(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int Cin, int gelu);
 
 // batch_invariant != 0: the kernel choice may depend on the SHAPE of one image only, never on B (bit-identical rows whatever the
 // batch they travel in); 0: the fastest kernel for this B (the VALU dw7x7 below the matrix-core kernel's fill threshold)
 // amax (may be null; honoured by the stride-1 7x7 kernels - the ConvFFN's depthwise conv - and by the RepMixer 3x3): see dwconv_tiled_kernel
 extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const float* w, const float* bias,
-                                  int B, int H, int W, int Cin, int K, int stride, int mult, int gelu, int batch_invariant, unsigned* amax)
+                                  int B, int H, int W, int Cin, int K, int stride, int mult, int gelu, int flags, unsigned* amax)
 {
+    // flags: bit 0 = batch_invariant (below); bit 1 = the taps are NOT bf16 numbers and must be applied as they are (fp32): the tower sets it
+    // for a depthwise conv whose packed taps differ from their bf16 rounding (an fp32 / fp16 checkpoint, or BatchNorm folded at load time) -
+    // honoured where a matrix-core kernel would otherwise be a NEW choice of round 6 (stride 2); the stride-1 7x7 rounds as it always did
+    const int batch_invariant = flags & 1;
+    const bool exact_taps = (flags & 2) != 0;
     const bf16* xi = (const bf16*)x;
     bf16* yo = (bf16*)y;
     const int Cout = Cin * mult;
@@ -373,6 +380,12 @@ extern "C" int fvhd_launch_dwconv(hipStream_t st, const void* x, void* y, const 
     // register-prefetch form of rounds 1-3 carried 8 spilled VGPRs in its tap loop at the 256-register limit; without the prefetch (loads
     // at the top of the tile, the other resident workgroups cover them) 309 -> 292 / 163 -> 149 / 42 -> 38 us at C = 96 / 192 / 768, and
     // 32-channel slices at 3 waves per SIMD 78 -> 65 us at C = 384.  Same accumulation order: identical bits.
+    // Round 6: the same conv on the matrix cores (dwconv_down.hip: stride 2 as two Toeplitz products over the even and the odd input pixels)
+    // wherever the input pixels come in whole 64-B pieces; a choice by shape (and by the taps being bf16 numbers: a re-parameterised bf16
+    // checkpoint, mci.py:442-451 - then the kernel's bf16 operands ARE the taps) only - the same bits whatever the batch.
+    // FVHD_DWDOWN_MFMA=0 in the environment keeps the VALU kernel below (A/B runs).
+    if (K == 7 && stride == 2 && mult == 2 && !exact_taps && fvhd_dw7s2_mfma_supported(B, H, W, Cin, 0))
+        return fvhd_launch_dw7s2_mfma(st, x, y, w, bias, B, H, W, Cin, gelu);
     if (K == 7 && stride == 2 && mult == 2 && gelu && c32) {
         if (Cin == 384 || !c64) return (int)launch_dw_tiled<7, 2, 2, true, 32, false, 3, 0>(st, xi, yo, w, bias, B, H, W, Cin);
         return (int)launch_dw_tiled<7, 2, 2, true, 64, false, 2, 0>(st, xi, yo, w, bias, B, H, W, Cin);

@@ -21,6 +21,7 @@ int fvhd_launch_dw7_mfma(hipStream_t, const void*, void*, const float*, const fl
 int fvhd_launch_preprocess(hipStream_t, const void*, int, int, long, int, int, unsigned, const int*, const int*, int, const int*, const int*, int, int, int,
                            void*, const float*, int, void*, int);
 int fvhd_dw7_mfma_supported(int, int, int, int, int);
+int fvhd_launch_dw7s2_mfma(hipStream_t, const void*, void*, const float*, const float*, int, int, int, int, int);
 int fvhd_launch_dw3_dw7(hipStream_t, const void*, void*, void*, const float*, const float*, const float*, const float*, int, int, int, int, unsigned*);
 int fvhd_launch_gemm(hipStream_t, const void*, const void*, const float*, const float*, const void*, void*, int, int, int, int, int);
 int fvhd_gemm_splitk_plan(int, int, int);
@@ -100,7 +101,7 @@ struct Packer {          // builds the packed weight image on the host; offsets 
     }
 };
 
-struct DwW { size_t w = 0, b = 0; int K = 0; };                    // taps fp32 [K*K][Cout], bias fp32 [Cout]
+struct DwW { size_t w = 0, b = 0; int K = 0; bool bf16_taps = false; };   // taps fp32 [K*K][Cout], bias fp32 [Cout]; bf16_taps: every packed tap is a bf16 number
 struct GemmW { size_t w = 0, b = 0; int N = 0, K = 0; bool has_bias = false; };
 // w?img: chunk images of the fused kernel in its two precisions ([0] FVHD_FFN_HALF: W1 / 4 in bf16, 4 W2 in f16; [1] FVHD_FFN_BF16);
 // precision: which one this block runs (fvhd_set_ffn_precision / fvhd_audit_ranges; FVHD_FFN_BF16 from the start if |4 W2| would overflow f16)
@@ -244,6 +245,12 @@ bool pack_dw(fvhd_ctx* c, Packer& pk, const std::string& wkey, const std::string
     out->w = pk.add_f32(t.data(), t.size());
     out->b = pk.add_f32(b.data(), b.size());
     out->K = K;
+    out->bf16_taps = true;                   // (a bf16 tower with re-parameterised convolutions: the taps a matrix-core kernel rounds to are the taps)
+    for (float v : t) {
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        if (u & 0xffffu) { out->bf16_taps = false; break; }
+    }
     return true;
 }
 
@@ -566,7 +573,8 @@ int run_dw(fvhd_ctx* c, hipStream_t st, int cls, const DwW& w, const void* x, vo
            int stride, int mult, int gelu, unsigned* amax = nullptr)
 {
     Scope s(c, st, cls);
-    CHECK_LAUNCH(fvhd_launch_dwconv(st, x, y, c->wp<float>(w.w), c->wp<float>(w.b), B, H, W, Cin, w.K, stride, mult, gelu, c->batch_invariant, amax),
+    CHECK_LAUNCH(fvhd_launch_dwconv(st, x, y, c->wp<float>(w.w), c->wp<float>(w.b), B, H, W, Cin, w.K, stride, mult, gelu,
+                                    (c->batch_invariant ? 1 : 0) | (w.bf16_taps ? 0 : 2), amax),
                  "dwconv launch");
     return 0;
 }
@@ -1379,6 +1387,17 @@ int fvhd_op_dw3_dw7(fvhd_stream_t st, const void* x, void* y, void* a, const flo
                     std::to_string(H) + " W=" + std::to_string(W) + " C=" + std::to_string(C) + ")");
     int e = fvhd_launch_dw3_dw7((hipStream_t)st, x, y, a, w3, b3, w7, b7, B, H, W, C, (unsigned*)amax_bits);
     return e ? hip_fail("fvhd_op_dw3_dw7", (hipError_t)e) : 0;
+}
+
+// PatchEmbed's dw7x7 / stride 2 / multiplier 2 + bias + GELU on the matrix-core kernel directly (also for maps the dispatcher leaves to the VALU kernel)
+int fvhd_op_dw7s2_mfma(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int Cin)
+{
+    if (!x || !y || !w) return fail("fvhd_op_dw7s2_mfma: NULL pointer");
+    if (!fvhd_dw7s2_mfma_supported(B, H, W, Cin, 1))
+        return fail("fvhd_op_dw7s2_mfma: needs Cin % 32 == 0, H, W >= 2 and images below 2 GiB (got B=" + std::to_string(B) + " H=" +
+                    std::to_string(H) + " W=" + std::to_string(W) + " Cin=" + std::to_string(Cin) + ")");
+    int e = fvhd_launch_dw7s2_mfma((hipStream_t)st, x, y, w, bias, B, H, W, Cin, 1);
+    return e ? hip_fail("fvhd_op_dw7s2_mfma", (hipError_t)e) : 0;
 }
 
 int fvhd_op_dw7_mfma(fvhd_stream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C)

@@ -395,6 +395,54 @@ def test_dwconv_matrix_core_kernel_random_shapes(seed):
     test_dwconv(7, 1, 1, 0, Cin, H, W, B, force_mfma=True)
 
 
+@pytest.mark.parametrize("Cin,H,W,B,gelu", [
+    (32, 16, 16, 1, 1),          # one workgroup, half a strip
+    (96, 64, 64, 2, 1),          # one full strip, three channel blocks
+    (64, 10, 130, 2, 1),         # three strips, the last one a single output pixel wide
+    (32, 33, 67, 3, 1),          # odd height and width
+    (192, 128, 128, 2, 1),       # stage 1 -> 2 of the 1024^2 tower: two strips, several row chunks
+    (768, 32, 32, 2, 1),         # stage 3 -> 4: half a strip masked
+    (96, 7, 5, 1, 1),            # map smaller than the kernel
+    (64, 150, 70, 1, 1),         # many row chunks, ragged second strip
+    (32, 2, 2, 2, 1),            # the smallest map
+])
+def test_dwconv_stride2_matrix_core_kernel(Cin, H, W, B, gelu, seed=1):
+    assert gelu == 1             # (the C ABI offers this conv with its activation only, as PatchEmbed uses it)
+    """PatchEmbed's dw7x7 / stride 2 / multiplier 2 on the 16-block MFMA (csrc/dwconv_down.hip).  Against the fp32 conv with the taps the
+    kernel uses (rounded to bf16): only the fp32 summation order, the GELU polynomial (1.3e-4 absolute) and the bf16 rounding of the result
+    are left - a wrong tap, pixel or row would be off by O(1); and within the common op tolerance of the conv with the fp32 taps."""
+    lib = _lib.load()
+    assert lib.fvhd_dw7s2_mfma_supported(B, H, W, Cin, 1) == 1
+    Cout = 2 * Cin
+    x = _bf(_rand(B, Cin, H, W, seed=seed))
+    w = _rand(Cout, 1, 7, 7, seed=seed + 1, scale=1.0 / 7)
+    b = _rand(Cout, seed=seed + 2, scale=0.2)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    y = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    wd, bd = _pack_dw(w).to(DEV), b.to(DEV)
+    if lib.fvhd_dw7s2_mfma_supported(B, H, W, Cin, 0) and seed % 2:      # the dispatcher's own route where it picks this kernel
+        _lib.check(lib.fvhd_op_dwconv(_stream(), _p(xn), _p(y), _p(wd), _p(bd), B, H, W, Cin, 7, 2, 2, 1), "dwconv s2")
+    else:
+        _lib.check(lib.fvhd_op_dw7s2_mfma(_stream(), _p(xn), _p(y), _p(wd), _p(bd), B, H, W, Cin), "dw7s2 mfma")
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).float().cpu()
+    assert torch.isfinite(got).all(), "an output element was not written"
+    act = O.gelu if gelu else (lambda t: t)
+    want_bf = act(F.conv2d(x.float(), _bf(w).float(), b, stride=2, padding=3, groups=Cin))
+    err = (got - want_bf).abs()
+    bound = 2.0 ** -8 * want_bf.abs() + 4e-4
+    assert (err <= bound).all(), f"max excess {(err - bound).max().item():.3e} at {torch.nonzero(err > bound)[:4].tolist()}"
+    _close(y.permute(0, 3, 1, 2), act(F.conv2d(x.float(), w, b, stride=2, padding=3, groups=Cin)), what="dwconv s2 vs fp32 taps")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_dwconv_stride2_matrix_core_kernel_random_shapes(seed):
+    import random
+    rnd = random.Random(2000 + seed)
+    test_dwconv_stride2_matrix_core_kernel(rnd.choice([32, 64, 96, 160]), rnd.randint(2, 90), rnd.randint(2, 140), rnd.randint(1, 3), 1, seed=seed)
+
+
 def _repmixer_taps(C, seed):
     """dw3x3 taps shaped like a re-parameterised RepMixer (mci.py:819-859): identity + small branches, i.e. a centre tap of 1 + eps -
     the case a single bf16 tap would get wrong by 2^-9 of x"""

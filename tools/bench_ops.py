@@ -196,6 +196,25 @@ def _bench_dw(B=32, only_k7=False, only_k3=False):
         print(f"dwconv K={K} S={S} mult={mult} C={Cc:4d} H={H:3d}: {t*1e6:9.1f} us  {by/t/1e9:7.1f} GB/s  {fl/t/1e12:6.2f} TF/s")
 
 
+def bench_dwdown(B=int(os.environ.get("BENCH_B", "32"))):
+    """PatchEmbed dw7x7 / stride 2 / multiplier 2 + GELU at the four stage boundaries (FVHD_DWDOWN_MFMA=0: the VALU kernel; debug library:
+    a sweep of the matrix-core kernel's rows per chunk)"""
+    raw = C.CDLL(_lib.LIB_PATH)
+    rcs = (0, 8, 16, 32, 64) if hasattr(raw, "fvhd_debug_set_dd_rc") else (0,)
+    for Cc, H in ((96, 256), (192, 128), (384, 64), (768, 32)):
+        x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+        y = torch.empty(B, H // 2, H // 2, 2 * Cc, device=DEV, dtype=torch.bfloat16)
+        w, bias = torch.randn(49, 2 * Cc, device=DEV) / 7, torch.randn(2 * Cc, device=DEV) * 0.2
+        by = 2.0 * (x.numel() + y.numel())
+        for rc in rcs:
+            if rc:
+                raw.fvhd_debug_set_dd_rc(rc)
+            t = timeit(lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 7, 2, 2, 1)))
+            print(f"dw_down Cin={Cc:4d} H={H:3d} B={B} mfma={lib.fvhd_dw7s2_mfma_supported(B, H, H, Cc, 0)} rows/chunk={rc or 'auto'}: {t*1e6:8.1f} us  {by/t/1e9:7.1f} GB/s")
+        if rcs != (0,):
+            raw.fvhd_debug_set_dd_rc(0)
+
+
 def bench_gemm(B=32):
     shapes = [("stem 1x1", B * 65536, 96, 96, 2), ("down0 1x1", B * 16384, 192, 192, 2), ("down1 1x1", B * 4096, 384, 384, 2),
               ("down2 1x1", B * 1024, 768, 768, 2), ("down3 1x1", B * 256, 1536, 1536, 2),
@@ -339,4 +358,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw7nw": bench_dw7nw, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn, "dw37": bench_dw37}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw7nw": bench_dw7nw, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn, "dw37": bench_dw37, "dwdown": bench_dwdown}[w]()

@@ -101,6 +101,41 @@ final)      # evidence of the final binary: bench line, small batches, PMC passe
     timeout 400 rocprofv3 --kernel-trace --output-format rocpd -d gpurun_out/${TAG}_ttft_trace -o ttft -- python bench.py --ttft --steps 4 --warmup 1 > gpurun_out/${TAG}_ttft_trace.log 2>&1
     python tools/rocpd_summary.py gpurun_out/${TAG}_ttft_trace/ttft_results.db > ${O}_ttft_kernel_trace.md 2>&1; rm -rf gpurun_out/${TAG}_ttft_trace; head -30 ${O}_ttft_kernel_trace.md | cut -c1-160
     ;;
+r6d)        # round 6: PatchEmbed's stride-2 depthwise conv on the matrix cores: op tests, VALU vs MFMA per shape, rows-per-chunk sweep, step tests, whole step A/B
+    timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dwconv" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
+    FVHD_DWDOWN_MFMA=0 timeout 200 python tools/bench_ops.py dwdown 2>&1 | grep -v Warning | tee ${O}_dwdown.log
+    timeout 200 python tools/bench_ops.py dwdown 2>&1 | grep -v Warning | tee -a ${O}_dwdown.log
+    [ -f ml_fastvlm_amd/libfvhd_ablate.so ] && FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so timeout 300 python tools/bench_ops.py dwdown 2>&1 | grep -v Warning | tee -a ${O}_dwdown.log
+    timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tower.py -m gpu -q --maxfail=15 > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -15 ${O}_pytest_steps.log | cut -c1-300
+    for v in 0 1 0 1; do
+        FVHD_DWDOWN_MFMA=$v timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_dd$v.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_dd$v.json")); print("FVHD_DWDOWN_MFMA=$v", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw") or k in ("gemm_1x1", "stem")}, d["conv_stage"]["frac"])
+PY
+    done
+    ;;
+r6e)        # round 6: dw_down ablations (variant libraries libfvhd_dd<bits>.so / _ddr4), attention V staging A/B (libfvhd_vtr0.so = the ds_write_b16 transposition)
+    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dwconv or attention" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -8 ${O}_pytest.log | cut -c1-400
+    for lib in base dd1 dd2 dd4 dd6 dd8 dd16 ddr4; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        [ -f $L ] || continue
+        echo "--- $lib" | tee -a ${O}_dwdown_abl.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dwdown 2>&1 | grep "dw_down" | tee -a ${O}_dwdown_abl.log
+    done
+    for lib in base vtr0 base vtr0; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        echo "--- $lib" | tee -a ${O}_attn_ab.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py attn 2>/dev/null | tee -a ${O}_attn_ab.log
+    done
+    timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tower.py -m gpu -q --maxfail=15 > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -5 ${O}_pytest_steps.log | cut -c1-300
+    for lib in base vtr0 base vtr0; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_$lib.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw") or k in ("attention", "stem")}, d["conv_stage"]["frac"], d["attention_block"]["frac"])
+PY
+    done
+    ;;
 r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
     timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log

@@ -29,7 +29,7 @@ CLASSES = [  # (class, regex on kernel name); first match wins
     ("dw7_s1", r"dwconv_tiled_kernelILi7ELi1ELi1E|dwconv_tiled_kernel<7, 1, 1"),
     ("dw3_s1", r"dwconv_tiled_kernelILi3ELi1ELi1E|dwconv_tiled_kernel<3, 1, 1"),
     ("dw_mixer_fused", r"dw3_dw7_kernel"),
-    ("dw_down", r"dwconv_tiled_kernelILi7ELi2ELi2E|dwconv_tiled_kernel<7, 2, 2"),
+    ("dw_down", r"dwconv_tiled_kernelILi7ELi2ELi2E|dwconv_tiled_kernel<7, 2, 2|dw7s2_mfma_kernel"),
     ("dw_head", r"dwconv_tiled_kernelILi3ELi1ELi2E|dwconv_tiled_kernel<3, 1, 2"),
     ("stem", r"stem_(fused|conv)_kernel|dwconv_tiled_kernelILi3ELi2ELi1E"),
     ("attention", r"attention_kernel"),
