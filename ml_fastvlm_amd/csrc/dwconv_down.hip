@@ -37,7 +37,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4p;
 #ifndef DD_RSP_
 #define DD_RSP_ 3
 #endif
-#ifndef DD_ABL                    // timing-only ablations (wrong results): 1 no MFMAs, 2 no transposing writes, 4 no GELU, 8 no stores, 16 no DMA in the loop
+#ifndef DD_ABL                    // timing-only ablations (wrong results): 1 no MFMAs, 2 no transposing writes, 4 no GELU, 8 no stores, 16 no DMA in the loop,
+                                  // 32 no per-iteration barrier (racy), 64 no LDS reads in the loop (raw pair, output row, operands)
 #define DD_ABL 0
 #endif
 constexpr int DD_RSP = DD_RSP_;   // raw ring depth in row PAIRS
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
             // own pieces of pair t + 1 have landed once at most the RSP - 2 later pairs' loads (4 per wave and pair) are outstanding (stores may
             // retire out of order with loads: counting only loads is the safe side); own LDS traffic of the previous iteration retired
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 * (RSP - 2)) : "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(DD_ABL & 32)) __builtin_amdgcn_s_barrier();
             const int nslot = slot + 1 == RSP ? 0 : slot + 1;
             s16x4 opv[2][8];
             u32x4 tv[4], ov;
@@ -243,8 +244,14 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) opv[rr][i] = opn[rr][i];
+            if (DD_ABL & 64) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { tv[i] = u32x4{1, 2, 3, 4}; asm volatile("" : "+v"(tv[i])); }
+                ov = tv[0];
+            } else {
             tr_read(tv, nslot);
             y_read(ov, yb ^ 1);                              // output row t - 2, staged in the previous iteration
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 56; ++k) {
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
                     }
                 }
                 if (k == 53) { *(u32x2*)&yw[yb * YE] = u32x2{pk[0], pk[1]}; *(u32x2*)&yw[yb * YE + 16] = u32x2{pk[2], pk[3]}; }
-                if (k == 54) op_fetch(t + 1);                // the next pair's operands (its transposing writes are all issued: same wave, in order)
+                if (!(DD_ABL & 64) && k == 54) op_fetch(t + 1);   // the next pair's operands (its transposing writes are all issued: same wave, in order)
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = nslot;

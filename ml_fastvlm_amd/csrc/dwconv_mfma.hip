@@ -70,18 +70,24 @@ constexpr int DWM_TSKEW = DWM_TSKEW_;
 #endif
 // NW waves per workgroup = NW adjacent channel groups = 16 NW channels: 4 (64 channels = one 128-B line per pixel; C = 192, 384, ...)
 // or 6 (96 channels: with C = 96 the whole row segment of the strip is contiguous in memory)
-template <int NW> struct DwmCfg {
+// NT tiles of 16 px per strip: 4 (64-px strips) or, round 6, 2 (32-px strips for maps at most 32 px wide - stages 3 and 4 of the tower, where
+// a 64-px strip is half / three quarters padding: every per-row cost of a wave halves with the strip)
+template <int NW, int NT = 4> struct DwmCfg {
+    static_assert(NT == 4 || (NT == 2 && NW == 4), "32-px strips: 64-channel workgroups only");
     static constexpr int CW = 16 * NW, PXB = CW * 2;          // channels / bytes per pixel of the workgroup's block
+    static constexpr int SW = 16 * NT, IWX = SW + 8;          // strip width, strip + halo columns
     static constexpr int OPX = PXB + DWM_OPAD_;               // output staging: one pixel + pad (the 4 pixels of one ds_write_b16 on 4 disjoint bank groups)
-    static constexpr int HALO = 64 * PXB;                     // byte offset of the halo pixels inside a raw row
-    static constexpr int RAWB = 72 * PXB, OB = 64 * OPX, TB = (16 * DWM_P + DWM_TSKEW) * 2;       // TB: one transposed image (+ the skew gap between its channel halves); two per wave
+    static constexpr int HALO = SW * PXB;                     // byte offset of the halo pixels inside a raw row
+    static constexpr int RAWB = IWX * PXB, OB = SW * OPX, TB = (16 * DWM_P + DWM_TSKEW) * 2;       // TB: one transposed image (+ the skew gap between its channel halves); two per wave
+    static constexpr int NLOAD = NT == 4 ? 3 : 2;             // LDS-DMA instructions per wave and row (interior pieces + halo)
+    static constexpr int NM = (IWX * 2 + 63) / 64;            // transposition rounds (16-B chunks of this wave's column / 64 lanes)
     static constexpr int NOB = (DWM_ABL & 128) ? 1 : 2;
     static constexpr int LDS = DWM_RS * RAWB + NOB * OB + NW * 2 * TB;
 };
 
 FVHD_DEV u16 f32_to_bf16_rne(float f) { unsigned u = __float_as_uint(f); u += 0x7fff + ((u >> 16) & 1); return (u16)(u >> 16); }
 
-template <int NW, bool AMAX>
+template <int NW, bool AMAX, int NT = 4>
 __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restrict__ x, u16* __restrict__ y, const float* __restrict__ w,
                                                               const float* __restrict__ bias, int H, int W, int C, int RC, int nstrip, int nchunk,
                                                               unsigned* amax)
@@ -90,8 +96,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     // strips (for W % 64 != 0 that includes up to 63 columns right of the image, computed from the zero padding: a superset, never less than
     // the image's own maximum), as fp32 bit patterns of non-negative numbers in a row of FVHD_AMAX_SLOTS words (fvhd_common.h) - the range
     // guard of the half-precision fused ConvFFN
-    using K = DwmCfg<NW>;
-    constexpr int NT = 4, CW = K::CW, PXB = K::PXB, SW = 64, IWX = 72, RS = DWM_RS, P = DWM_P, OPX = K::OPX, RAWB = K::RAWB, OB = K::OB, TBY = K::TB, TE = TBY / 2, SK = DWM_TSKEW;   // TE: u16 elements of one transposed image
+    using K = DwmCfg<NW, NT>;
+    constexpr int CW = K::CW, PXB = K::PXB, SW = K::SW, IWX = K::IWX, NM = K::NM, RS = DWM_RS, P = DWM_P, OPX = K::OPX, RAWB = K::RAWB, OB = K::OB, TBY = K::TB, TE = TBY / 2, SK = DWM_TSKEW;   // TE: u16 elements of one transposed image
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* raw = smem;                                       // [RS][64 interior px | 8 halo px][PXB]  (NW = 4: chunks permuted inside every 1-KiB piece)
@@ -139,20 +145,26 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * C + cb * CW) * 2 + off); };
     unsigned vint0, vint1;
     if constexpr (NW == 4) {
-        const int ipx = x0 + 16 * wv + ((lane >> 1) & 7), off = (lane >> 4) * 32 + (lane & 1) * 16;
-        vint0 = goff(ipx, off); vint1 = goff(ipx + 8, off);
+        const int ipx = x0 + (NT == 4 ? 16 : 8) * wv + ((lane >> 1) & 7), off = (lane >> 4) * 32 + (lane & 1) * 16;
+        vint0 = goff(ipx, off); vint1 = goff(ipx + 8, off);          // (NT == 2: one piece per wave, vint1 unused)
     } else {
         const int b0 = 2048 * wv + 16 * lane, b1 = b0 + 1024;
         vint0 = goff(x0 + b0 / PXB, b0 % PXB); vint1 = goff(x0 + b1 / PXB, b1 % PXB);
     }
     const int hb = 256 * wv + 16 * (lane & 15), hp = hb / PXB;
-    const unsigned vhalo = goff(hp < 4 ? x0 - 4 + hp : x0 + 60 + hp, hb % PXB);
+    const unsigned vhalo = goff(hp < 4 ? x0 - 4 + hp : x0 + SW - 4 + hp, hb % PXB);
     const unsigned raw_lds = lds_addr(raw);
     auto dma = [&](int r, int slot) {
         const char* rb = ximg + (size_t)r * row_bytes;
-        const unsigned d0 = raw_lds + slot * RAWB + 2048 * wv, dh = raw_lds + slot * RAWB + K::HALO + 256 * wv;
+        const unsigned d0 = raw_lds + slot * RAWB + (NT == 4 ? 2048 : 1024) * wv, dh = raw_lds + slot * RAWB + K::HALO + 256 * wv;
         unsigned keep; unsigned long long ex;
         // M0 = LDS destination of the piece (+ lane * 16 by the hardware); the halo piece runs on lanes 0..15; s_add_u32 clobbers SCC
+        if constexpr (NT == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+                         "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+                         "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep), "=&s"(ex) : "v"(vint0), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb) : "memory", "scc");
+        else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
                      "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
                      "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
@@ -160,30 +172,30 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                      : "=&s"(keep), "=&s"(ex) : "v"(vint0), "v"(vint1), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb) : "memory", "scc");
     };
     // ---- transposition source offsets / validity of this lane's three 16-B chunks (T column 32 m + lane / 2, channel half lane & 1)
-    unsigned roff[3];
-    bool okm[3];
+    unsigned roff[NM];
+    bool okm[NM];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < NM; ++m) {
         const int col = 32 * m + (lane >> 1), xi = x0 - 4 + col;
         okm[m] = col < IWX && xi >= 0 && xi < W;
         const int cc = min(col, IWX - 1), ip = cc - 4;
         const int sub = wv * 32 + (lane & 1) * 16;
-        roff[m] = (unsigned)(cc < 4 ? K::HALO + cc * PXB + sub : cc >= 68 ? K::HALO + (cc - 64) * PXB + sub
+        roff[m] = (unsigned)(cc < 4 ? K::HALO + cc * PXB + sub : cc >= SW + 4 ? K::HALO + (cc - SW) * PXB + sub
                                     : NW == 4 ? (ip >> 3) * 1024 + wv * 256 + (ip & 7) * 32 + (lane & 1) * 16 : ip * PXB + sub);
     }
     // transposition in two halves so that the row loop can put MFMAs between the reads and the writes.  The writes are
     // unconditional (no EXEC juggling inside the MFMA stream): lanes without a pixel of the image - halo columns outside it, lanes
     // >= 16 of the third chunk - write into the 8 spare columns 72..79 of the pitch instead, and the columns outside the image keep
     // their zeros.
-    unsigned tdst[3];                          // u16 index inside one T buffer
+    unsigned tdst[NM];                         // u16 index inside one T buffer (okm: col < IWX, i.e. not the lanes past the last chunk of the last round)
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-        tdst[m] = (unsigned)((8 * (lane & 1)) * P + SK * (lane & 1) + ((okm[m] && !(m == 2 && lane >= 16)) ? 32 * m + (lane >> 1) : IWX + ((lane >> 1) & 7)));
-    auto tr_read = [&](u32x4 (&v)[3], int slot) {
+    for (int m = 0; m < NM; ++m)
+        tdst[m] = (unsigned)((8 * (lane & 1)) * P + SK * (lane & 1) + (okm[m] ? 32 * m + (lane >> 1) : IWX + ((lane >> 1) & 7)));
+    auto tr_read = [&](u32x4 (&v)[NM], int slot) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) v[m] = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
+        for (int m = 0; m < NM; ++m) v[m] = __builtin_bit_cast(u32x4, *(const u16x8*)(raw + slot * RAWB + roff[m]));
     };
-    auto tr_write1 = [&](const u32x4 (&v)[3], int tb, int m, int e) {       // element e (channel 8 half + e) of chunk m
+    auto tr_write1 = [&](const u32x4 (&v)[NM], int tb, int m, int e) {      // element e (channel 8 half + e) of chunk m
         u16* d = T + tb * TE + tdst[m];
         const unsigned wv_ = e < 2 ? v[m].x : e < 4 ? v[m].y : e < 6 ? v[m].z : v[m].w;
         d[e * P] = (e & 1) ? (u16)(wv_ >> 16) : (u16)wv_;
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     }
     // ---- output: own 16 channels into the shared row buffer; then this wave stores 2 of the 2 NW 1-KiB pieces of the row (whole
     // lines).  Pixels right of the image and rows above the chunk get an out-of-range buffer offset (dropped by the range check).
-    const int sb0 = 2048 * wv + 16 * lane, sb1 = sb0 + 1024;                 // byte inside the [64 px][PXB] output row
+    const int sb0 = (NT == 4 ? 2048 : 1024) * wv + 16 * lane, sb1 = sb0 + 1024;   // byte inside the [SW px][PXB] output row (NT == 2: one piece per wave, sb1 unused)
     const int spx0 = x0 + sb0 / PXB, spx1 = x0 + sb1 / PXB;
     const unsigned vst0 = goff(spx0, sb0 % PXB), oob0 = spx0 < W ? 0u : 0x80000000u;
     const unsigned vst1 = goff(spx1, sb1 % PXB), oob1 = spx1 < W ? 0u : 0x80000000u;
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
             pk[2 * t + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a[t][2], a[t][3]}, bf16x2_t));
         }
     };
-    auto stage_write1 = [&](const unsigned (&pk)[2 * NT], int ob, int j) {  // j = 0..15: pixel 16 (j / 4) + 4 (j % 4) + q
+    auto stage_write1 = [&](const unsigned (&pk)[2 * NT], int ob, int j) {  // j = 0..4 NT - 1: pixel 16 (j / 4) + 4 (j % 4) + q
         u16* Ow = (u16*)(O + (ob & (K::NOB - 1)) * OB + q * OPX + wv * 32 + blk * 2);
         const unsigned v = pk[j >> 1];
         Ow[(16 * (j >> 2) + 4 * (j & 3)) * (OPX / 2)] = (j & 1) ? (u16)(v >> 16) : (u16)v;
@@ -215,17 +227,17 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
         unsigned pk[2 * NT];
         stage_cvt(pk, a);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) stage_write1(pk, ob, j);
+        for (int j = 0; j < 4 * NT; ++j) stage_write1(pk, ob, j);
     };
     auto o_read = [&](u32x4 (&o)[2], int ob) {
         // same element type as the ds_write_b16 side (strict aliasing: a u32x4 load was hoisted above the u16 stores)
         o[0] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + (ob & (K::NOB - 1)) * OB + ord0));
-        o[1] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + (ob & (K::NOB - 1)) * OB + ord1));
+        if constexpr (NT == 4) o[1] = __builtin_bit_cast(u32x4, *(const u16x8*)(O + (ob & (K::NOB - 1)) * OB + ord1));
     };
     auto o_store = [&](const u32x4 (&o)[2], int yo) {
         const unsigned ro = (unsigned)max(yo, 0) * row_bytes, oobr = yo >= ylo ? 0u : 0x80000000u;     // valid offsets are < 2^31: the flags are OR-ed in
         __builtin_amdgcn_raw_buffer_store_b128(o[0], ry, (vst0 + ro) | oob0 | oobr, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o[1], ry, (vst1 + ro) | oob1 | oobr, 0, 0);
+        if constexpr (NT == 4) __builtin_amdgcn_raw_buffer_store_b128(o[1], ry, (vst1 + ro) | oob1 | oobr, 0, 0);
     };
 
     // ---- rows.  Input rows [r_lo, r_hi); the slot of output row yo is (yo - r_lo + 3) % 7, so the unrolled sequence starts at u = 0.
@@ -242,10 +254,10 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
-        u32x4 v[3];
+        u32x4 v[NM];
         tr_read(v, r_lo % RS);
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int e = 0; e < 8; ++e) tr_write1(v, 0, m, e);
     }
@@ -256,17 +268,19 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
         for (int u = 0; u < 7; ++u) {
             // own pieces of row r + 1 have landed once at most the RS - 2 later rows' pieces are outstanding (only loads are
             // counted: stores may retire ahead of older loads); own staging writes of the previous iteration retired
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(3 * (RS - 2)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(K::NLOAD * (RS - 2)) : "memory");
             if (!(DWM_ABL & 4)) __builtin_amdgcn_s_barrier();
             const int nslot = slot + 1 == RS ? 0 : slot + 1;
             s16x4 a[3][NT];                                     // A operands of the three segments
-            u32x4 tv[3], ov[2];
+            u32x4 tv[NM], ov[2];
             unsigned pk[2 * NT];
             if (DWM_ABL & 64) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { a[0][t] = s16x4{1, 2, 3, 4}; a[1][t] = a[0][t]; a[2][t] = a[0][t]; asm volatile("" : "+v"(a[0][t]), "+v"(a[1][t]), "+v"(a[2][t])); }
-                tv[0] = tv[1] = tv[2] = u32x4{1, 2, 3, 4}; ov[0] = ov[1] = tv[0];
-                asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(ov[0]), "+v"(ov[1]));
+#pragma unroll
+                for (int m = 0; m < NM; ++m) { tv[m] = u32x4{1, 2, 3, 4}; asm volatile("" : "+v"(tv[m])); }
+                ov[0] = ov[1] = tv[0];
+                asm volatile("" : "+v"(ov[0]), "+v"(ov[1]));
             } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) a[0][t] = *(const s16x4*)&rd[tb * TE + 16 * t];
@@ -280,9 +294,11 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
             // without branches: rows outside [ylo, yhi) are never stored, their slot is re-initialised before its next owner's
             // first contribution.  The row's other instructions are dealt out ONE PER MFMA behind fixed positions of the stream
             // (an 8-cycle MFMA leaves one issue slot): they overlap the matrix pipe inside the wave instead of stalling in bursts.
+            // (positions for NT = 4 in the comments; NT = 2: the 42-MFMA stream with the same instructions at the scaled positions)
+            constexpr int NK = 21 * NT, KS = 7 * NT, KF = 2 * KS + NT + 2;     // KF: the finished slot's last update was MFMA 2 KS .. 2 KS + NT - 1
 #pragma unroll
-            for (int k = 0; k < 84; ++k) {
-                const int s = k / 28, ky = 6 - (k % 28) / 4, t = k % 4;
+            for (int k = 0; k < NK; ++k) {
+                const int s = k / KS, ky = 6 - (k % KS) / NT, t = k % NT;
                 // a slot starts its life (output row r + 3: ky = 0 of segment 0) with C = the bias quad instead of being re-initialised
                 // by VALU moves: the register allocator placed those moves directly in front of the MFMA that reads them, and an
                 // inline-asm MFMA gets no VALU-write -> MFMA-read wait states from the compiler (wrong sums in 2 of 4 registers)
@@ -300,27 +316,29 @@ __global__ __launch_bounds__(64 * NW, 2) void dw7_mfma_kernel(const u16* __restr
                 if (!(DWM_ABL & 32) && k == 8) dma(min(r + RS, r_hi - 1), slot);   // row r's slot: every wave transposed it before this iteration's barrier
                 if (!(DWM_ABL & 1) && k >= 10 && k < 18) tr_write1(tv, tb ^ 1, 0, k - 10);
                 if (!(DWM_ABL & 1) && k >= 18 && k < 26) tr_write1(tv, tb ^ 1, 1, k - 18);
-                if (!(DWM_ABL & 64) && k == 30) {
+                if (!(DWM_ABL & 64) && k == KS + 2) {
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) a[2][tt] = *(const s16x4*)&rd[tb * TE + 16 * tt + 8];
                 }
-                if (!(DWM_ABL & 1) && k >= 32 && k < 40) tr_write1(tv, tb ^ 1, 2, k - 32);
-                if (k == 62) {
+                if constexpr (NM == 3) {
+                    if (!(DWM_ABL & 1) && k >= 32 && k < 40) tr_write1(tv, tb ^ 1, 2, k - 32);
+                }
+                if (k == KF) {
                     // the slot's last update was MFMA 56..59: pin its readers behind the stream position (the compiler does not
                     // know the asm statements are MFMAs and once scheduled the first v_cvt right behind the last MFMA: stale registers)
                     asm volatile("" : "+v"(acc[u][0]), "+v"(acc[u][1]), "+v"(acc[u][2]), "+v"(acc[u][3]));
                     stage_cvt(pk, acc[u]);
                 }
-                if (!(DWM_ABL & 2) && k >= 64 && k < 80) stage_write1(pk, ob, k - 64);
+                if (!(DWM_ABL & 2) && k >= KF + 2 && k < KF + 2 + 4 * NT) stage_write1(pk, ob, k - (KF + 2));
                 // max |.| of the finished row (its 16 accumulators: final since MFMA 59, pinned at k = 62), two v_max3_f32 per free slot;
                 // rows above the chunk (their slots hold partial sums and are never stored) do not count
-                if (AMAX && k == 63) cand = 0.f;
-                if (AMAX && (k == 63 || (k >= 80 && k < 83))) {
-                    const int t = k == 63 ? 0 : k - 79;
+                if (AMAX && k == KF + 1) cand = 0.f;
+                if (AMAX && (k == KF + 1 || (k >= NK - NT && k < NK - 1))) {
+                    const int t = k == KF + 1 ? 0 : k - (NK - NT) + 1;
                     cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t][0])), __builtin_fabsf(acc[u][t][1]));
                     cand = __builtin_fmaxf(__builtin_fmaxf(cand, __builtin_fabsf(acc[u][t][2])), __builtin_fabsf(acc[u][t][3]));
                 }
-                if (AMAX && k == 83) amx = (r - 3 >= ylo) ? __builtin_fmaxf(amx, cand) : amx;
+                if (AMAX && k == NK - 1) amx = (r - 3 >= ylo) ? __builtin_fmaxf(amx, cand) : amx;
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = nslot;
@@ -385,39 +403,46 @@ done:
 #ifdef FVHD_DEBUG_KNOBS
 static int g_dwm_rc = 0;                                     // > 0: rows per chunk forced (tools/bench_ops.py dw7small)
 static int g_dwm_nw = 0;                                     // 6: the 96-channel workgroup wherever C % 96 == 0 (tools/bench_ops.py dw7nw)
+static int g_dwm_nt = 0;                                     // 4: 64-px strips also for maps at most 32 px wide (A/B of the 32-px strips)
 extern "C" void fvhd_debug_set_dwm_rc(int rc) { g_dwm_rc = rc; }
 extern "C" void fvhd_debug_set_dwm_nw(int nw) { g_dwm_nw = nw; }
+extern "C" void fvhd_debug_set_dwm_nt(int nt) { g_dwm_nt = nt; }
 #else
-static constexpr int g_dwm_rc = 0, g_dwm_nw = 0;
+static constexpr int g_dwm_rc = 0, g_dwm_nw = 0, g_dwm_nt = 0;
 #endif
+
+// 32-px strips (round 6) for maps at most 32 px wide with 64-channel workgroups: stages 3 and 4 of the tower (B = 32: 48.9 -> ... us per launch
+// at 768 @32x32, profiles/r06_dw7_strip32.log)
+static bool dwm_strip32(int W, int C) { return W <= 32 && C % 64 == 0 && !(g_dwm_nw == 6 && C % 96 == 0) && g_dwm_nt != 4; }
 
 static int dwm_rows_per_chunk(int B, int H, int W, int C)
 {
     if (g_dwm_rc > 0) return g_dwm_rc;
     const int nw = (C % 64 == 0 && !(g_dwm_nw == 6 && C % 96 == 0)) ? 4 : 6;
-    const long long per_row_chunk = (long long)B * (C / (16 * nw)) * ((W + 63) / 64);
+    const int sw = dwm_strip32(W, C) ? 32 : 64;
+    const long long per_row_chunk = (long long)B * (C / (16 * nw)) * ((W + sw - 1) / sw);
     if (per_row_chunk * ((H + 31) / 32) >= 192) return 32;
     if (per_row_chunk * ((H + 15) / 16) >= 192) return 16;
     if (per_row_chunk * ((H + 7) / 8) >= 192) return 8;
     return 0;
 }
 
-template <int NW, bool AMAX>
+template <int NW, bool AMAX, int NT = 4>
 static int launch_dwm(hipStream_t st, const void* x, void* y, const float* w, const float* bias, int B, int H, int W, int C, unsigned* amax)
 {
     static bool attr_set[64] = {};                           // per device (one process may drive several contexts)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_set[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute((const void*)dw7_mfma_kernel<NW, AMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, DwmCfg<NW>::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)dw7_mfma_kernel<NW, AMAX, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, DwmCfg<NW, NT>::LDS);
         if (e != hipSuccess) return (int)e;
         attr_set[dev & 63] = true;
     }
     const int rc_ = dwm_rows_per_chunk(B, H, W, C), RC = rc_ > 0 ? rc_ : 8;
-    const int nstrip = (W + 63) / 64, nchunk = (H + RC - 1) / RC;
+    const int nstrip = (W + 16 * NT - 1) / (16 * NT), nchunk = (H + RC - 1) / RC;
     const long long grid = (long long)B * (C / (16 * NW)) * nstrip * nchunk;
     if (grid <= 0 || grid > 0x7fffffffll) return (int)hipErrorInvalidValue;
-    dw7_mfma_kernel<NW, AMAX><<<(int)grid, 64 * NW, DwmCfg<NW>::LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk, amax);
+    dw7_mfma_kernel<NW, AMAX, NT><<<(int)grid, 64 * NW, DwmCfg<NW, NT>::LDS, st>>>((const u16*)x, (u16*)y, w, bias, H, W, C, RC, nstrip, nchunk, amax);
     return (int)hipGetLastError();
 }
 
@@ -428,7 +453,7 @@ extern "C" int fvhd_dw7_mfma_supported(int B, int H, int W, int C, int force)
     if (force) return 1;
     // narrower maps run the same 64-px strip with masked columns: still ahead of the VALU kernel down to W = 24 (B = 32, C = 768 @32x32:
     // 54 vs 62 us; 48x48: 57 vs 83; C = 1536 @24x24: 42 vs 53), behind it at W = 16 (47 vs 34: three quarters of the strip is padding)
-    return W >= 24 && dwm_rows_per_chunk(B, H, W, C) > 0;
+    return (W >= 24 || (dwm_strip32(W, C) && W >= 12)) && dwm_rows_per_chunk(B, H, W, C) > 0;
 }
 
 // x, y [B, H, W, C] bf16 (NHWC); w fp32 [49][C]; bias fp32 [C] or null
@@ -436,6 +461,7 @@ extern "C" int fvhd_launch_dw7_mfma(hipStream_t st, const void* x, void* y, cons
 {
     if (!fvhd_dw7_mfma_supported(B, H, W, C, 1)) return (int)hipErrorInvalidValue;
     const bool nw4 = C % 64 == 0 && !(g_dwm_nw == 6 && C % 96 == 0);
+    if (dwm_strip32(W, C)) return amax ? launch_dwm<4, true, 2>(st, x, y, w, bias, B, H, W, C, amax) : launch_dwm<4, false, 2>(st, x, y, w, bias, B, H, W, C, nullptr);
     if (amax) return nw4 ? launch_dwm<4, true>(st, x, y, w, bias, B, H, W, C, amax) : launch_dwm<6, true>(st, x, y, w, bias, B, H, W, C, amax);
     return nw4 ? launch_dwm<4, false>(st, x, y, w, bias, B, H, W, C, nullptr) : launch_dwm<6, false>(st, x, y, w, bias, B, H, W, C, nullptr);
 }

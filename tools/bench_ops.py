@@ -215,6 +215,25 @@ def bench_dwdown(B=int(os.environ.get("BENCH_B", "32"))):
             raw.fvhd_debug_set_dd_rc(0)
 
 
+def bench_dw7s34(B=int(os.environ.get("BENCH_B", "32"))):
+    """the stride-1 dw7x7 launches of stages 3 and 4 (RepCPE, ConvFFN.conv): 32-px strips (round 6) against the 64-px strips / the VALU kernel
+    (debug library: fvhd_debug_set_dwm_nt(4) restores the round-5 dispatch)"""
+    raw = C.CDLL(_lib.LIB_PATH)
+    nts = (0, 4, 0, 4) if hasattr(raw, "fvhd_debug_set_dwm_nt") else (0,)
+    for Cc, H in ((768, 32), (1536, 16), (384, 32), (768, 16)):
+        x = torch.randn(B, H, H, Cc).to(DEV, torch.bfloat16)
+        y = torch.empty_like(x)
+        w, bias = torch.randn(49, Cc, device=DEV) / 7, torch.randn(Cc, device=DEV) * 0.2
+        by = 4.0 * x.numel()
+        for nt in nts:
+            if len(nts) > 1:
+                raw.fvhd_debug_set_dwm_nt(nt)
+            t = timeit(lambda: _lib.check(lib.fvhd_op_dwconv(stream(), p(x), p(y), p(w), p(bias), B, H, H, Cc, 7, 1, 1, 0)))
+            print(f"dw7 C={Cc:4d} H={H:3d} B={B} strips={'round-5 dispatch' if nt == 4 else 'default (32-px strips for maps <= 32 px)'}: {t*1e6:8.1f} us  {by/t/1e9:7.1f} GB/s")
+    if len(nts) > 1:
+        raw.fvhd_debug_set_dwm_nt(0)
+
+
 def bench_gemm(B=32):
     shapes = [("stem 1x1", B * 65536, 96, 96, 2), ("down0 1x1", B * 16384, 192, 192, 2), ("down1 1x1", B * 4096, 384, 384, 2),
               ("down2 1x1", B * 1024, 768, 768, 2), ("down3 1x1", B * 256, 1536, 1536, 2),
@@ -358,4 +377,4 @@ def bench_attn(B=32):
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if a != "all"] or ["ffn", "dw", "gemm", "attn"]
     for w in which:
-        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw7nw": bench_dw7nw, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn, "dw37": bench_dw37, "dwdown": bench_dwdown}[w]()
+        {"ffn": bench_ffn, "dw": bench_dw, "dw_ablate": lambda: bench_dw(modes=(0, 1, 2)), "stem": bench_stem, "dwraw": _bench_dw, "dw7cfg": bench_dw7cfg, "dw7small": bench_dw7small, "dw7nw": bench_dw7nw, "dw3cfg": bench_dw3cfg, "gemm": bench_gemm, "gemmsmall": bench_gemmsmall, "attn": bench_attn, "dw37": bench_dw37, "dwdown": bench_dwdown, "dw7s34": bench_dw7s34}[w]()

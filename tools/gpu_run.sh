@@ -136,6 +136,29 @@ d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["va
 PY
     done
     ;;
+r6f)        # round 6: dw_down skeleton ablations, dw7x7 with 32-px strips (stages 3 / 4) A/B through the debug library, attention V staging A/B
+    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dwconv or attention or dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -8 ${O}_pytest.log | cut -c1-400
+    for lib in base dd31 dd63 dd95 dd127 base; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        [ -f $L ] || continue
+        echo "--- $lib" | tee -a ${O}_dwdown_abl.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dwdown 2>&1 | grep "dw_down" | tee -a ${O}_dwdown_abl.log
+    done
+    FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so timeout 300 python tools/bench_ops.py dw7s34 2>&1 | grep "dw7 " | tee ${O}_dw7_strip32.log
+    for lib in base vtr0 base vtr0; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        echo "--- $lib" | tee -a ${O}_attn_ab.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py attn 2>&1 | grep "attention" | tee -a ${O}_attn_ab.log
+    done
+    for lib in base vtr0 base vtr0; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_$lib.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw") or k in ("attention", "stem")}, d["conv_stage"]["frac"], d["attention_block"]["frac"])
+PY
+    done
+    timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tower.py -m gpu -q --maxfail=15 > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -5 ${O}_pytest_steps.log | cut -c1-300
+    ;;
 r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
     timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
