@@ -59,23 +59,21 @@ struct DdCfg {
 
 FVHD_DEV u16 dd_bf16_rne(float f) { unsigned u = __float_as_uint(f); u += 0x7fff + ((u >> 16) & 1); return (u16)(u >> 16); }
 
-// the 56 MFMAs of one iteration, in issue order.  Groups (input row parity, tap row) -> output row: G0 (even, 5) and G1 (odd, 6) finish row t - 1
-// (slot 0), G2 (even, 3) / G3 (odd, 4) row t (slot 1), G4 (even, 1) / G5 (odd, 2) row t + 1 (slot 2), G6 (odd, 0) starts row t + 2 (slot 3).
-// MFMAs 0..31 alternate between the finishing row and row t (an accumulator is updated every 4th MFMA; the finishing row is complete after
-// MFMA 30 and its epilogue runs beside the rest), 32..55 go A A B over rows t + 1 and t + 2.
+// the 56 MFMAs of one iteration, in issue order.  Groups (input row parity, tap row) -> output row: (even, 5) and (odd, 6) finish row t - 1
+// (slot 0), (even, 3) / (odd, 4) row t (slot 1), (even, 1) / (odd, 2) row t + 1 (slot 2), (odd, 0) starts row t + 2 (slot 3).
+// MFMAs 0..23: the EVEN input row (tap rows 5, 3, 1: six accumulators in turn) - its operand registers are free from MFMA 24 on and take the
+// next pair's even row during the rest of the iteration; 24..39: the odd row's tap rows 6 and 4 alternating (the finishing row is complete
+// after MFMA 38 and its epilogue runs beside the rest); 40..55: tap rows 2 and 0 alternating.
 struct DdStep { int row, ky, slot, op, tile; };       // row: 0 = even input row, 1 = odd; op: 0 O centre, 1 O next, 2 E' centre, 3 E' next
 constexpr DdStep dd_step(int k)
 {
-    if (k < 32) {
-        const int which = k & 1, j = k >> 1, tile = j & 1, opg = j >> 1, odd = opg & 1, op = opg >> 1;
-        return which == 0 ? DdStep{odd, odd ? 6 : 5, 0, op, tile} : DdStep{odd, odd ? 4 : 3, 1, op, tile};
+    if (k < 24) {
+        const int op = k / 6, rem = k % 6, grp = rem >> 1, tile = rem & 1;
+        return DdStep{0, 5 - 2 * grp, grp, op, tile};
     }
-    const int m = k - 32, tri = m / 3, pos = m % 3;
-    if (pos < 2) {
-        const int a = 2 * tri + pos, tile = a & 1, opg = a >> 1, odd = opg & 1, op = opg >> 1;
-        return DdStep{odd, odd ? 2 : 1, 2, op, tile};
-    }
-    return DdStep{1, 0, 3, tri >> 1, tri & 1};
+    const int j = (k - 24) & 15, late = (k - 24) >> 4, which = j & 1, jj = j >> 1, tile = jj & 1, op = jj >> 1;
+    return late == 0 ? (which == 0 ? DdStep{1, 6, 0, op, tile} : DdStep{1, 4, 1, op, tile})
+                     : (which == 0 ? DdStep{1, 2, 2, op, tile} : DdStep{1, 0, 3, op, tile});
 }
 
 template <bool ACT>
@@ -127,23 +125,30 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) { acc[sl][0] = biasq; acc[sl][1] = biasq; }
 
-    // ---- LDS-DMA of one input row: interior piece wv (16 px x 64 B, stored [consumer wave][px][16 B]: a wave's later 16-B column reads are
-    // contiguous) and this wave's own 16-B column of the 8 halo pixels (lanes 0..7).  Pixels / rows outside the image load a clamped address.
+    // ---- LDS-DMA: waves 0 and 1 bring in the pair's even / odd row - four interior pieces (16 px x 64 B each, stored [consumer wave][px][16 B]: a
+    // wave's later 16-B column reads are contiguous) and the 8 halo pixels as [consumer wave][px][16 B] on 32 lanes.  Waves 2 and 3 issue the
+    // stores.  So a wave's vmcnt counts ONE kind: with loads and stores in one wave "at most N outstanding" cannot tell an old store from a
+    // young load, and the row barrier ended up waiting for a store or a load issued one iteration earlier (a full memory round trip per row).
+    // Pixels / rows outside the image load a clamped address.
     auto goff = [&](int px, int off) { return (unsigned)((min(max(px, 0), W - 1) * Cin + cb * 32) * 2 + off); };
-    const unsigned vint = goff(xi0 + wv * 16 + (lane & 15), (lane >> 4) * 16);
-    const unsigned vhalo = goff((lane & 7) < 4 ? xi0 - 4 + (lane & 7) : xi0 + 60 + (lane & 7), wv * 16);
+    unsigned vint[4];
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) vint[pi] = goff(xi0 + pi * 16 + (lane & 15), (lane >> 4) * 16);
+    const unsigned vhalo = goff((lane & 7) < 4 ? xi0 - 4 + (lane & 7) : xi0 + 60 + (lane & 7), ((lane >> 3) & 3) * 16);
     const unsigned raw_lds = lds_addr(raw);
-    auto dma_pair = [&](int t, int slot) {                  // input rows 2 t, 2 t + 1
-        const char* rb0 = ximg + (size_t)min(max(2 * t, 0), H - 1) * row_bytes;
-        const char* rb1 = ximg + (size_t)min(max(2 * t + 1, 0), H - 1) * row_bytes;
-        const unsigned d0 = raw_lds + slot * PAIRB + 1024 * wv, dh0 = raw_lds + slot * PAIRB + 64 * PXB + 128 * wv;
+    const unsigned long long lanes32 = 0xffffffffull;
+    auto dma_row = [&](int t, int slot) {                   // waves 0, 1: input row 2 t + wv into its half of ring slot `slot`
+        const char* rb = ximg + (size_t)min(max(2 * t + wv, 0), H - 1) * row_bytes;
+        const unsigned d0 = raw_lds + slot * PAIRB + wv * ROWB, dh = d0 + 64 * PXB;
         unsigned keep; unsigned long long ex;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
-                     "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
-                     "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xff\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
-                     "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
+                     "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %9\n\t"
+                     "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
+                     "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %9\n\t"
+                     "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %10\n\ts_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %9\n\t"
                      "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&s"(ex) : "v"(vint), "v"(vhalo), "s"(d0), "s"(dh0), "s"(rb0), "s"(rb1), "n"(ROWB) : "memory", "scc");
+                     : "=&s"(keep), "=&s"(ex)
+                     : "v"(vint[0]), "v"(vint[1]), "v"(vint[2]), "v"(vint[3]), "v"(vhalo), "s"(d0), "s"(dh), "s"(rb), "s"(lanes32) : "memory", "scc");
     };
     // ---- transposition raw row -> T: round 0: lane = interior pixel (window column lane + 4); round 1: lanes 0..7 = the halo pixels
     // (columns 0..3 and 68..71).  Column c goes to plane E' index c / 2 - 1 (c even) or plane O index (c - 1) / 2 (c odd); columns outside the
@@ -176,46 +181,53 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
     }
     // ---- pixel operands: lane (b, q) reads 4 pixels of input channel b / 2: plane p, index 16 tile + 4 q (+ 4 for the next segment)
     const u16* rd = T + (blk >> 1) * CHE + 4 * q;
-    s16x4 opn[2][8];                                         // [row of the pair][2 (2 plane + next) ... see op_index] fetched one iteration ahead
-    auto op_fetch = [&](int t) {                             // operands of pair t (already transposed in T); rows outside the image: the zero image
+    s16x4 opv[2][8];                                         // [row of the pair][4 tile + op]; each row is refilled as soon as its MFMAs are through
+    auto op_fetch = [&](int t, int rr) {                     // operands of row rr of pair t (already transposed in T); a row outside the image: the zero image
         asm volatile("" ::: "memory");
+        const int r = 2 * t + rr;
+        const int ib = (r >= 0 && r < H) ? rr * TE : zrel;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * t + rr;
-            const int ib = (r >= 0 && r < H) ? rr * TE : zrel;
+        for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
-            for (int tile = 0; tile < 2; ++tile)
-#pragma unroll
-                for (int op = 0; op < 4; ++op)              // op: 0 O centre, 1 O next, 2 E' centre, 3 E' next
-                    opn[rr][tile * 4 + op] = *(const s16x4*)&rd[ib + ((op < 2) ? PP : 0) + 16 * tile + 4 * (op & 1)];
-        }
+            for (int op = 0; op < 4; ++op)                  // op: 0 O centre, 1 O next, 2 E' centre, 3 E' next
+                opv[rr][tile * 4 + op] = *(const s16x4*)&rd[ib + ((op < 2) ? PP : 0) + 16 * tile + 4 * (op & 1)];
         asm volatile("" ::: "memory");
     };
     // ---- output: this wave's finished row goes into Y[buf] as [16 ch][32 px] (one 8-byte write per tile); one iteration later (all four
-    // waves' images complete behind the barrier) every wave stores 8 pixels x 64 channels = 8 whole lines, read back transposed:
+    // waves' images complete behind the barrier) waves 2 and 3 store 16 pixels x 64 channels = 16 whole lines each, read back transposed:
     // source lane (g, j, c): 4 consecutive pixels of row 8 (so & 1) + j (+ 4 for the second read) of wave (so >> 1)'s image, so = (4 g + c) & 7,
-    // pixel quad 8 wv + 4 ((4 g + c) >> 3); output lane (g, c = (lane >> 2) & 3, e = lane & 3): 16-B chunk (4 g + c) & 7 of pixel
-    // 8 wv + 4 ((4 g + c) >> 3) + e.
+    // pixel quad 16 sw + 8 h + 4 ((4 g + c) >> 3); output lane (g, c = (lane >> 2) & 3, e = lane & 3): 16-B chunk (4 g + c) & 7 of pixel
+    // 16 sw + 8 h + 4 ((4 g + c) >> 3) + e   (sw = wv - 2, h = 0, 1: the two store instructions).
     u16* yw = Y + blk * YP + YSK * (blk >> 3) + 4 * q;
+    const int sw = wv & 1;
     const int ss = 4 * (lane >> 4) + (lane & 3), so = ss & 7, sj = (lane >> 2) & 3, sr = 8 * (so & 1) + sj;
-    const unsigned trsrc = y_lds + (unsigned)((so >> 1) * K::WSY + (sr * YP + YSK * (sr >> 3) + 8 * wv + 4 * (ss >> 3)) * 2);
-    const int ds_ = 4 * (lane >> 4) + ((lane >> 2) & 3), dpx = xo0 + 8 * wv + 4 * (ds_ >> 3) + (lane & 3);
-    const unsigned vst = (unsigned)((min(dpx, OW - 1) * Cout + cb * 64) * 2 + (ds_ & 7) * 16), oobx = dpx < OW ? 0u : 0x80000000u;
-    auto y_read = [&](u32x4& o, int buf) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(size_t)(trsrc + buf * K::YB));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(size_t)(trsrc + buf * K::YB + 8 * YP));
-        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-        o = u32x4{l2.x, l2.y, h2.x, h2.y};
+    const unsigned trsrc = y_lds + (unsigned)((so >> 1) * K::WSY + (sr * YP + YSK * (sr >> 3) + 16 * sw + 4 * (ss >> 3)) * 2);
+    const int ds_ = 4 * (lane >> 4) + ((lane >> 2) & 3), dpx = xo0 + 16 * sw + 4 * (ds_ >> 3) + (lane & 3);
+    const unsigned vst0 = (unsigned)((min(dpx, OW - 1) * Cout + cb * 64) * 2 + (ds_ & 7) * 16), oobx0 = dpx < OW ? 0u : 0x80000000u;
+    const unsigned vst1 = (unsigned)((min(dpx + 8, OW - 1) * Cout + cb * 64) * 2 + (ds_ & 7) * 16), oobx1 = dpx + 8 < OW ? 0u : 0x80000000u;
+    auto y_read = [&](u32x4 (&o)[2], int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(size_t)(trsrc + buf * K::YB + 16 * h));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(size_t)(trsrc + buf * K::YB + 16 * h + 8 * YP));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            o[h] = u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
     };
-    auto y_store = [&](const u32x4& o, int yo) {
+    auto y_store = [&](const u32x4 (&o)[2], int yo) {
         const unsigned ro = (unsigned)min(max(yo, 0), OH - 1) * orow_bytes, oobr = (yo >= ylo && yo < yhi) ? 0u : 0x80000000u;
-        if (!(DD_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b128(o, ry, (vst + ro) | oobx | oobr, 0, 0);
+        if (!(DD_ABL & 8)) {
+            __builtin_amdgcn_raw_buffer_store_b128(o[0], ry, (vst0 + ro) | oobx0 | oobr, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[1], ry, (vst1 + ro) | oobx1 | oobr, 0, 0);
+        }
     };
 
     // ---- rows.  Iterations t = ylo - 2 .. yhi; pair t lives in ring slot (t - t0) % RSP.
     const int t0 = ylo - 2, t1 = yhi;
+    if (wv < 2) {
 #pragma unroll
-    for (int i = 0; i < RSP; ++i) dma_pair(t0 + i, i);
+        for (int i = 0; i < RSP; ++i) dma_row(t0 + i, i);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
@@ -226,31 +238,27 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) tr_write1(v, i, e);
     }
-    op_fetch(t0);
+    op_fetch(t0, 0);
+    op_fetch(t0, 1);
     int t = t0, slot = 0, yb = 0;
     for (;;) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // own pieces of pair t + 1 have landed once at most the RSP - 2 later pairs' loads (4 per wave and pair) are outstanding (stores may
-            // retire out of order with loads: counting only loads is the safe side); own LDS traffic of the previous iteration retired
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 * (RSP - 2)) : "memory");
+            // waves 0, 1: own row of pair t + 1 has landed once at most the RSP - 2 later rows' loads (5 each) are outstanding; waves 2, 3 (stores
+            // only, two per iteration): never more than 2.5 iterations of stores in flight; own LDS traffic of the previous iteration retired
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(5 * (RSP - 2)) : "memory");
             if (!(DD_ABL & 32)) __builtin_amdgcn_s_barrier();
             const int nslot = slot + 1 == RSP ? 0 : slot + 1;
-            s16x4 opv[2][8];
-            u32x4 tv[4], ov;
+            u32x4 tv[4], ov[2];
             f32x4 fin[2];
             unsigned pk[4];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) opv[rr][i] = opn[rr][i];
             if (DD_ABL & 64) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { tv[i] = u32x4{1, 2, 3, 4}; asm volatile("" : "+v"(tv[i])); }
-                ov = tv[0];
+                ov[0] = ov[1] = tv[0];
             } else {
-            tr_read(tv, nslot);
-            y_read(ov, yb ^ 1);                              // output row t - 2, staged in the previous iteration
+                if (wv >= 2) y_read(ov, yb ^ 1);             // output row t - 2, staged in the previous iteration
+                tr_read(tv, nslot);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -265,15 +273,16 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
                     asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %3" : "=&v"(acc[sl][s.tile]) : "v"(bop[s.ky][s.op]), "v"(opv[s.row][s.tile * 4 + s.op]), "v"(biasq));
                 else
                     asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+v"(acc[sl][s.tile]) : "v"(bop[s.ky][s.op]), "v"(opv[s.row][s.tile * 4 + s.op]));
-                if (k == 4) y_store(ov, t - 2);
-                if (!(DD_ABL & 16) && k == 6) dma_pair(t + RSP, slot);       // pair t's slot: every wave transposed it before this iteration's barrier
+                if (!(DD_ABL & 16) && k == 3 && wv < 2) dma_row(t + RSP, slot);    // pair t's slot: every wave transposed it before this iteration's barrier
+                if (k == 6 && wv >= 2) y_store(ov, t - 2);
                 if (!(DD_ABL & 2) && k >= 8 && k < 40) tr_write1(tv, (k - 8) >> 3, (k - 8) & 7);
-                if (k == 34) {                               // the finishing row's last update was MFMA 30: its readers stay behind this point
+                if (!(DD_ABL & 64) && k == 26) op_fetch(t + 1, 0);           // the even row's registers are free (MFMAs 0..23), its image is written (k = 8..23)
+                if (k == 42) {                               // the finishing row's last update was MFMA 38: its readers stay behind this point
                     asm volatile("" : "+v"(acc[u][0]), "+v"(acc[u][1]));
                     fin[0] = acc[u][0]; fin[1] = acc[u][1];
                 }
-                if (ACT && !(DD_ABL & 4) && k >= 36 && k < 52 && ((k - 36) & 1) == 0) {
-                    const int v = (k - 36) >> 1;
+                if (ACT && !(DD_ABL & 4) && k >= 43 && k < 51) {
+                    const int v = k - 43;
                     fin[v >> 2][v & 3] = gelu_erf(fin[v >> 2][v & 3]);
                 }
                 if (k == 52) {
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
                     }
                 }
                 if (k == 53) { *(u32x2*)&yw[yb * YE] = u32x2{pk[0], pk[1]}; *(u32x2*)&yw[yb * YE + 16] = u32x2{pk[2], pk[3]}; }
-                if (!(DD_ABL & 64) && k == 54) op_fetch(t + 1);   // the next pair's operands (its transposing writes are all issued: same wave, in order)
+                if (!(DD_ABL & 64) && k == 55) op_fetch(t + 1, 1);   // the odd row's operands (its transposing writes are all issued: same wave, in order)
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot = nslot;
@@ -296,9 +305,11 @@ done:
     {   // the row staged by the last iteration (output row t1 - 1 = yhi - 1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        u32x4 ov;
-        y_read(ov, yb ^ 1);
-        y_store(ov, t1 - 1);
+        if (wv >= 2) {
+            u32x4 ov[2];
+            y_read(ov, yb ^ 1);
+            y_store(ov, t1 - 1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may be in flight when the LDS is released
 }

@@ -7,19 +7,16 @@ rng = np.random.default_rng(0)
 
 
 def dd_step(k):
-    if k < 32:
-        which, j = k & 1, k >> 1
-        tile, opg = j & 1, j >> 1
-        odd, op = opg & 1, opg >> 1
-        return (odd, 6 if odd else 5, 0, op, tile) if which == 0 else (odd, 4 if odd else 3, 1, op, tile)
-    m = k - 32
-    tri, pos = divmod(m, 3)
-    if pos < 2:
-        a = 2 * tri + pos
-        tile, opg = a & 1, a >> 1
-        odd, op = opg & 1, opg >> 1
-        return (odd, 2 if odd else 1, 2, op, tile)
-    return (1, 0, 3, tri >> 1, tri & 1)
+    if k < 24:
+        op, rem = divmod(k, 6)
+        grp, tile = rem >> 1, rem & 1
+        return (0, 5 - 2 * grp, grp, op, tile)
+    j, late = (k - 24) & 15, (k - 24) >> 4
+    which, jj = j & 1, j >> 1
+    tile, op = jj & 1, jj >> 1
+    if late == 0:
+        return (1, 6, 0, op, tile) if which == 0 else (1, 4, 1, op, tile)
+    return (1, 2, 2, op, tile) if which == 0 else (1, 0, 3, op, tile)
 
 
 def run(H, W, strip, ylo, yhi):
@@ -99,21 +96,25 @@ def store_map():
         for blk in range(16):
             for px in range(32):
                 img[wv * WSYe + blk * YP + YSK * (blk >> 3) + px] = 1000 * px + 16 * wv + blk
-    for wv in range(4):
+    seen = set()
+    for sw in range(2):                                          # store waves 2, 3
+      for hh in range(2):                                        # the two store instructions
         for h in range(2):                                       # lo / hi read
             src = {}
             for lane in range(64):
                 ss = 4 * (lane >> 4) + (lane & 3); so = ss & 7; sj = (lane >> 2) & 3; sr = 8 * (so & 1) + sj
-                src[lane] = (so >> 1) * WSYe + (sr + 4 * h) * YP + YSK * (sr >> 3) + 8 * wv + 4 * (ss >> 3)
+                src[lane] = (so >> 1) * WSYe + (sr + 4 * h) * YP + YSK * (sr >> 3) + 16 * sw + 8 * hh + 4 * (ss >> 3)
             for lane in range(64):
                 g = lane >> 4
                 ds_ = 4 * g + ((lane >> 2) & 3)
-                px = 8 * wv + 4 * (ds_ >> 3) + (lane & 3)
+                px = 16 * sw + 8 * hh + 4 * (ds_ >> 3) + (lane & 3)
                 for j in range(4):
                     sl = 16 * g + 4 * j + ((lane >> 2) & 3)
                     got = img[src[sl] + (lane & 3)]
                     want = 1000 * px + 8 * (ds_ & 7) + 4 * h + j
-                    assert got == want, (wv, h, lane, j, got, want)
+                    assert got == want, (sw, hh, h, lane, j, got, want)
+                    seen.add(got)
+    assert len(seen) == 32 * 64
     print("store map: ok")
 
 

@@ -159,6 +159,24 @@ PY
     done
     timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tower.py -m gpu -q --maxfail=15 > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -5 ${O}_pytest_steps.log | cut -c1-300
     ;;
+r6g)        # round 6: dw_down with DMA / store wave roles and per-row operand refill against the first version (libfvhd_ddold.so)
+    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dwconv" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -8 ${O}_pytest.log | cut -c1-400
+    for lib in base ddold base ddold; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        [ -f $L ] || continue
+        echo "--- $lib" | tee -a ${O}_dwdown_ab.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dwdown 2>&1 | grep "dw_down" | tee -a ${O}_dwdown_ab.log
+    done
+    FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so timeout 300 python tools/bench_ops.py dwdown 2>&1 | grep "dw_down" | tee ${O}_dwdown_rc.log
+    for lib in base ddold base ddold; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_$lib.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw") or k in ("attention", "stem")}, d["conv_stage"]["frac"], d["attention_block"]["frac"])
+PY
+    done
+    timeout 900 python -m pytest tests/test_gpu_steps.py -m gpu -q --maxfail=15 > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -5 ${O}_pytest_steps.log | cut -c1-300
+    ;;
 r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
     timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
