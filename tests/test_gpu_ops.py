@@ -559,6 +559,8 @@ def test_dwconv_no_bias():
     (96, 37, 70, 3, 1),          # ... 96-channel workgroups
     (64, 3, 64, 1, 1),           # ... fewer rows than taps: every output row comes from the tail loop
     (384, 64, 64, 24, 1),        # ... 16-row chunks (the shape class of stage 2)
+    (128, 40, 32, 2, 1),         # ... 32-px strips (maps at most 32 px wide, 64-channel workgroups: round 6)
+    (64, 21, 20, 3, 1),          # ... 32-px strip, ragged (the maximum is taken over the strip's 32 columns)
     (192, 11, 9, 2, 0),          # VALU kernel: one ragged tile
     (96, 40, 37, 2, 0),          # ... 96 channels, several tiles, LDS-DMA variant
     (768, 12, 12, 1, 0),         # ... register-staged variant (C = 768)
@@ -588,7 +590,8 @@ def test_dw7_amax_for_the_range_guard(Cin, H, W, B, mfma):
     got = bits.view(torch.float32).max().item()
     assert (bits >= 0).all(), "bit patterns of non-negative numbers"
     wq = _bf(w).float() if mfma else w                       # the matrix-core kernel rounds its taps to bf16
-    Wext = -(-W // 64) * 64 if mfma else W
+    sw = 32 if (W <= 32 and Cin % 64 == 0) else 64            # strip width of the matrix-core kernel (dwconv_mfma.hip: dwm_strip32)
+    Wext = -(-W // sw) * sw if mfma else W
     xe = F.pad(x.float(), (0, Wext - W))                     # zeros right of the image: what the masked columns of a strip see
     want = F.conv2d(xe, wq, b, padding=3, groups=Cin)[..., :Wext].abs().max().item()
     inside = F.conv2d(x.float(), wq, b, padding=3, groups=Cin).abs().max().item()
