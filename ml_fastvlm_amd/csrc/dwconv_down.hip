@@ -87,7 +87,13 @@ __global__ __launch_bounds__(256, 3) void dw7s2_mfma_kernel(const u16* __restric
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = lane >> 2, q = lane & 3;
     const int Cout = 2 * Cin, NCB = Cin / 32;
-    int L = blockIdx.x;
+    // the NCB channel blocks of one (image, chunk, strip) read the 64-B halves (thirds at C_in = 96) of the SAME 128-B lines: consecutive logical
+    // ids, and xcd_remap gives every XCD a contiguous range of them - siblings share an L2 (block id b runs on XCD b % 8: with cb as the fastest
+    // digit of the raw id every line was fetched into two or three L2s)
+#ifndef DD_XCD
+#define DD_XCD 1
+#endif
+    int L = DD_XCD ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const int cb = L % NCB; L /= NCB;
     const int strip = L % nstrip; L /= nstrip;
     const int chunk = L % nchunk;

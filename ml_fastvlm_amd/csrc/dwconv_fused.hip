@@ -113,10 +113,16 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
     // C % 64 == 32 (C = 96: 192-B pixels): the last 64-channel block is half real.  Its lanes outside the C channels read the block's first
     // half a second time (valid addresses, finite values), convolve with a clamped channel's taps, and never store; the waves of those
     // channels stay out of the guard's maximum.  1.33x the work of 96 channels - still ahead of the two launches (profiles/r06_dw_mix_c96.log).
-    const int NCB = (C + CW - 1) / CW, cb = (int)blockIdx.x % NCB, c0 = cb * CW + wq * 16;
+    // (C % 64 != 0: the channel blocks of a pixel share 128-B lines - 192-B pixels.  xcd_remap hands every XCD a contiguous range of logical
+    // ids, so the blocks of one run of rows - consecutive ids - work behind ONE L2 instead of fetching / writing every shared line through two)
+#ifndef FZ_XCD
+#define FZ_XCD 1
+#endif
+    const int bid = (FZ_XCD && (C % CW) != 0) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int NCB = (C + CW - 1) / CW, cb = bid % NCB, c0 = cb * CW + wq * 16;
     const int chv = min(c0 + blk, C - 1);                    // the channel whose taps this lane loads
     const bool wave_real = c0 < C;
-    int g0 = ((int)blockIdx.x / NCB) * rows_per_wg;
+    int g0 = (bid / NCB) * rows_per_wg;
     const int g1 = min(g0 + rows_per_wg, total_rows);
     char* raw = smem;                                        // [RS][64 interior px | 8 halo px][PXB]
     // Whole-line stores of a finished row straight from its [ch][px] image (T_y for y, O_A for A), transposed by the LDS read:

@@ -177,6 +177,22 @@ PY
     done
     timeout 900 python -m pytest tests/test_gpu_steps.py -m gpu -q --maxfail=15 > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -5 ${O}_pytest_steps.log | cut -c1-300
     ;;
+r6h)        # round 6: XCD-aware block order where channel blocks share 128-B lines (dw_down: 64-B pieces; dw_mix at C = 96) against libfvhd_x0.so (raw order)
+    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dwconv or dw3_dw7 or dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log | cut -c1-400
+    for lib in base x0 base x0; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        echo "--- $lib" | tee -a ${O}_xcd_ab.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dwdown 2>&1 | grep "dw_down" | tee -a ${O}_xcd_ab.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dw37 2>&1 | grep -i "96\|fused" | head -6 | tee -a ${O}_xcd_ab.log
+    done
+    for lib in base x0 base x0; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_$lib.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw") or k in ("stem",)}, d["conv_stage"]["frac"])
+PY
+    done
+    ;;
 r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
     timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
