@@ -117,8 +117,13 @@ def test_oracle_matches_live_reference_odd_shapes(synth_sd):
     ref = tower(x)
     assert ref.shape == (1, 9, 3072)
     assert _rel_l2(O.tower_forward(x, synth_sd), ref) < 2e-6
+    # fp64 at 128 px (2 x 2 tokens): torch's double-precision convolutions take ten minutes at 192 px on these cores, seconds at 128
+    tower = ref_import.build_reference_tower(128)
+    tower.vision_tower.model.load_state_dict(synth_sd, strict=True)
     tower.double()
+    x = synth.synthetic_images(1, 128, seed=5)
     ref64 = tower(x.double())
+    assert ref64.shape == (1, 4, 3072)
     got64 = O.tower_forward(x.double(), synth_sd, dtype=torch.float64)
     assert _rel_l2(got64, ref64) < 1e-12
 
