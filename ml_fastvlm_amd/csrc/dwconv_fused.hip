@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void dw3_dw7_kernel(const u16* __restrict__
 #ifndef FZ_XCD
 #define FZ_XCD 1
 #endif
-    const int bid = (FZ_XCD && (C % CW) != 0) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int bid = ((FZ_XCD == 1 && (C % CW) != 0) || FZ_XCD == 2) ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;    // (2: always - A/B)
     const int NCB = (C + CW - 1) / CW, cb = bid % NCB, c0 = cb * CW + wq * 16;
     const int chv = min(c0 + blk, C - 1);                    // the channel whose taps this lane loads
     const bool wave_real = c0 < C;

@@ -730,6 +730,7 @@ extern "C" void fvhd_debug_set_gemm_v2(int on) { g_gemm_v2 = on; }
 #else
 static constexpr int g_gemm_v2 = 1;
 #endif
+static const int g_gemm_nf6 = [] { const char* e = getenv("FVHD_GEMM_NF6"); return e ? atoi(e) : 1; }();    // A/B switch (round 6)
 
 template <int EPI, int ODT, int NWV, int BN = 128, int BKT = 64, int ABL = 0>
 static hipError_t launch_gemm256(hipStream_t st, const bf16* A, const bf16* Wt, const float* bias, const float* ls,
@@ -1095,6 +1096,10 @@ extern "C" int fvhd_launch_gemm(hipStream_t st, const void* A, const void* Wt, c
     const bool nf3 = (N % 128 != 0) && (N % 96 == 0);
     const bool bk64 = (K % 64 == 0);
     hipError_t e;
+    // N = 192 with many row tiles (PatchEmbed's 1x1 + GELU after stage 0: M = B * 16384): ONE 128 x 192 tile per row block instead of two
+    // 128 x 96 tiles - A is read once and the tile count halves; same K order per output element (identical bits).  Round 6, FVHD_GEMM_NF6=0: off.
+    if (g_gemm_nf6 && nf3 && bk64 && N % 192 == 0 && epi == EPI_BIAS_GELU && out_dtype == FVHD_BF16 && (long long)((M + 127) / 128) * (N / 192) >= 4ll * cu_count())
+        return (int)launch_gemm<6, 64, EPI_BIAS_GELU, FVHD_BF16>(st, a, w, bias, ls, r, out, M, N, K);
     if (nf3) e = bk64 ? dispatch_epi<3, 64>(st, a, w, bias, ls, r, out, M, N, K, epi, out_dtype)
                       : dispatch_epi<3, 32>(st, a, w, bias, ls, r, out, M, N, K, epi, out_dtype);
     else     e = bk64 ? dispatch_epi<4, 64>(st, a, w, bias, ls, r, out, M, N, K, epi, out_dtype)

@@ -87,6 +87,7 @@ def test_gemm_identity_asymmetric():
     (300, 96, 96, _lib.EPI_BIAS_GELU),          # NF=3 BK=32, ragged M   (stem 1x1, stage-0 fc2 shape class)
     (256, 384, 96, _lib.EPI_BIAS_GELU),         # NF=4 BK=32             (stage-0 fc1)
     (513, 192, 384, _lib.EPI_BIAS_LS_RESID),    # NF=3 BK=64, ragged M   (fc2 + layer scale + residual)
+    (131072 + 40, 192, 192, _lib.EPI_BIAS_GELU),  # 128 x 192 tiles (round 6: N = 192 with >= 4 tiles per CU - PatchEmbed's 1x1 after stage 0), ragged M
     (1000, 2304, 768, _lib.EPI_NONE),           # qkv, no bias
     (77, 768, 3072, _lib.EPI_BIAS_LS_RESID),    # stage-3 fc2, long K
     (64, 896, 3072, _lib.EPI_BIAS),             # projector

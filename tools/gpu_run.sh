@@ -193,6 +193,20 @@ d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["va
 PY
     done
     ;;
+r6i)        # round 6: 128 x 192 tiles for the N = 192 1x1 + GELU of PatchEmbed (FVHD_GEMM_NF6=0 / 1), bits and time
+    timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "gemm" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 ${O}_pytest.log | cut -c1-300
+    for v in 1 0 1 0; do
+        echo "--- FVHD_GEMM_NF6=$v" | tee -a ${O}_nf6.log
+        FVHD_LIB=ml_fastvlm_amd/libfvhd_ablate.so FVHD_GEMM_NF6=$v BENCH_GEMM_VARIANTS=1 timeout 200 python tools/bench_ops.py gemm 2>&1 | grep "1x1" | tee -a ${O}_nf6.log
+    done
+    for v in 1 0 1 0; do
+        FVHD_GEMM_NF6=$v timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_nf6_$v.json 2>/dev/null; python - <<PY | tee -a ${O}_ab.log
+import json
+d=json.load(open("${O}_bench_nf6_$v.json")); print("FVHD_GEMM_NF6=$v", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("gemm")})
+PY
+    done
+    timeout 600 python -m pytest tests/test_gpu_steps.py -m gpu -q --maxfail=15 -k "bench_batch or r1024" > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -3 ${O}_pytest_steps.log | cut -c1-300
+    ;;
 r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
     timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
