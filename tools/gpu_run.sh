@@ -207,6 +207,17 @@ PY
     done
     timeout 600 python -m pytest tests/test_gpu_steps.py -m gpu -q --maxfail=15 -k "bench_batch or r1024" > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -3 ${O}_pytest_steps.log | cut -c1-300
     ;;
+r6j)        # round 6: XCD-remapped block order in the depthwise pair for EVERY channel count (libfvhd_fzx2.so) against the default (C % 64 != 0 only)
+    for lib in base fzx2 base fzx2; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        echo "--- $lib" | tee -a ${O}_fzx2.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dw37 2>&1 | grep "dw3+dw7" | cut -c1-140 | tee -a ${O}_fzx2.log
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_$lib.json 2>/dev/null; python - <<PY | tee -a ${O}_fzx2.log
+import json
+d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw")}, d["conv_stage"]["frac"])
+PY
+    done
+    ;;
 r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
     timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
