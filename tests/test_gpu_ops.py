@@ -463,8 +463,10 @@ def _repmixer_taps(C, seed):
     (128, 17, 16, 2, True),      # the narrowest map
     (64, 50, 132, 1, False),     # third strip 4 px wide
     (192, 128, 128, 12, True),   # large enough for the tower's own dispatch (32-row chunks)
-    (96, 40, 64, 2, True),       # C % 64 == 32 (stage 0: 192-B pixels): the second channel block is half real - masked stores, clamped taps,
+    (96, 40, 64, 2, True),       # C % 64 == 32 (stage 0: 192-B pixels): the 32-channel block takes pairs of strips (here: one strip, the pair's second is absent),
     (96, 33, 132, 1, False),     # its waves kept out of the guard's maximum
+    (96, 70, 256, 2, True),      # ... four strips = two strip pairs of the 32-channel block (round 6: two strips x 32 channels per workgroup), several row runs
+    (288, 19, 200, 1, True),     # ... four full blocks + the 32-channel block, ragged last strip (two pairs)
     (288, 21, 48, 2, True),      # 4.5 channel blocks
 ])
 def test_dw3_dw7_fused_kernel(C, H, W, B, amax):

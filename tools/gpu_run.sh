@@ -218,6 +218,19 @@ d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["va
 PY
     done
     ;;
+r6k)        # round 6: the 32-channel block of the depthwise pair on pairs of strips (C = 96) (a patch that is not shipped: profiles/r06_dw_mix_c96_two_strips.patch; base = the patched build, fzold = the shipped kernel)
+    timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=30 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -12 ${O}_pytest.log | cut -c1-300
+    for lib in base fzold base fzold; do
+        [ "$lib" = base ] && L=ml_fastvlm_amd/libfvhd.so || L=ml_fastvlm_amd/libfvhd_$lib.so
+        echo "--- $lib" | tee -a ${O}_half2.log
+        FVHD_LIB=$L timeout 200 python tools/bench_ops.py dw37 2>&1 | grep "dw3+dw7" | cut -c1-140 | tee -a ${O}_half2.log
+        FVHD_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-ttft --no-extra-configs > ${O}_bench_$lib.json 2>/dev/null; python - <<PY | tee -a ${O}_half2.log
+import json
+d=json.load(open("${O}_bench_$lib.json")); print("$lib", d["ms_per_step"], d["value"], {k:v["ms_per_step"] for k,v in d["kernels"].items() if k.startswith("dw")}, d["conv_stage"]["frac"])
+PY
+    done
+    timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_ffn_precision.py -m gpu -q --maxfail=15 > ${O}_pytest_steps.log 2>&1; echo "pytest steps rc=$?"; tail -4 ${O}_pytest_steps.log | cut -c1-300
+    ;;
 r6a)        # round 6: the fused dw3x3 -> dw7x7 kernel: op tests, then fused vs two launches (+ rows-per-chunk sweep with the debug library)
     timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "dw3_dw7" --maxfail=20 > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -25 ${O}_pytest.log | cut -c1-400
     timeout 300 python tools/bench_ops.py dw37 2>&1 | grep -v Warning | tee ${O}_dw37.log
